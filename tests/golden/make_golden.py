@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Run ONLY in the build container (needs /root/reference and the installed ``transformers``):
+
+    python tests/golden/make_golden.py
+
+What runs (nothing here is copied into the repo - only numeric outputs are written):
+  * reference wrapper  /root/reference/models/model.py (TOD_ASR_Transformer_STC), heads
+    /root/reference/models/modules/hierarchical_classifier.py, optimizer
+    /root/reference/models/optimization.py (BertAdam), /root/reference/utils/STC_util.py,
+    /root/reference/utils/fscore.py - imported read-only (sys.dont_write_bytecode);
+  * cal_ce_loss / cal_total_loss / pred_one_sample: the text slice n_best_asr_bert.py:145-229 is
+    exec'd from the reference file at run time (the module itself does not import with the installed
+    transformers - ordinary ImportError);
+  * encoder: installed transformers BertModel / XLMRobertaModel (eager attention) built from an
+    in-memory config, weights = nbest_amd.synth.model_state(seed) (the build's own generator).
+
+It also asserts that oracle/ reproduces the reference on every case (this is what pins the oracle).
+Fixtures: label_space.json, kat.json, case_*.npz (inputs are regenerated from seeds at test time;
+the .npz hold expected outputs and the seeds/shapes needed to regenerate the inputs).
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(1, REF)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import nbest_amd  # noqa: F401
+from nbest_amd import config as ncfg, synth
+from oracle.encoder import EncoderConfig as OCfg
+from oracle.model import OracleModel
+from oracle.bertadam import OracleBertAdam
+from oracle import stc as ostc
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def load_reference():
+    import models.model as ref_model
+    import models.optimization as ref_optim
+    import utils.STC_util as ref_stc
+    import utils.fscore as ref_fscore
+    src = open(os.path.join(REF, "n_best_asr_bert.py")).read()
+    body = src[src.index("def cal_ce_loss"):src.index("def filter_informative")]
+    ns = dict(np=np, torch=torch, nn=nn, convert_labels=ref_stc.convert_labels,
+              onehot_to_scalar=ref_stc.onehot_to_scalar)
+    exec(compile(body, "n_best_asr_bert.py[145:216]", "exec"), ns)
+    return ref_model, ref_optim, ref_stc, ref_fscore, ns
+
+
+def hf_encoder(cfg):
+    import transformers
+    kw = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+              num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+              max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+              layer_norm_eps=cfg.layer_norm_eps, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+              pad_token_id=cfg.pad_token_id, attn_implementation="eager")
+    if cfg.family == "xlm-roberta":
+        c = transformers.XLMRobertaConfig(bos_token_id=0, eos_token_id=2, **kw)
+        return transformers.XLMRobertaModel(c)
+    return transformers.BertModel(transformers.BertConfig(**kw))
+
+
+def main():
+    ref_model, ref_optim, ref_stc, ref_fscore, ns = load_reference()
+    memory = torch.load(os.path.join(REF, "dstc2_data/processed_data/raw/memory.pt"))
+    t2b = {int(k): [int(x) for x in v] for k, v in memory["top2bottom_dict"].items()}
+    idx2label = [memory["idx2label"][i] for i in range(len(memory["idx2label"]))]
+    with open(os.path.join(HERE, "label_space.json"), "w") as f:
+        json.dump(dict(top2bottom={str(k): v for k, v in t2b.items()}, idx2label=idx2label,
+                       idx2toplabel=[memory["idx2toplabel"][i] for i in range(len(memory["idx2toplabel"]))]), f)
+    labels = ncfg.LabelSpace(t2b, idx2label)
+    b2t_ref = ref_stc.reverse_top2bottom(memory["top2bottom_dict"])
+    memory["bottom2top_mat"] = b2t_ref
+
+    # ---- known-answer tests held by the reference itself ----
+    kat = dict(
+        onehot_to_scalar=dict(inp=[[0, 0, 0], [0, 1, 0], [0, 0, 0], [0, 0, 0], [1, 0, 0]],
+                              out=ref_stc.onehot_to_scalar(torch.tensor(
+                                  [[0., 0, 0], [0, 1, 0], [0, 0, 0], [0, 0, 0], [1, 0, 0]])).tolist()),
+        update_f1=[dict(pred=["a", "b"], gold=["b", "c"], out=list(ref_fscore.update_f1(["a", "b"], ["b", "c"], 0, 0, 0))),
+                   dict(pred=[], gold=["x"], out=list(ref_fscore.update_f1([], ["x"], 2, 3, 4)))],
+        compute_f1=[dict(inp=[1, 1, 1], out=list(ref_fscore.compute_f1(1, 1, 1))),
+                    dict(inp=[0, 5, 7], out=list(ref_fscore.compute_f1(0, 5, 7))),
+                    dict(inp=[7, 2, 3], out=list(ref_fscore.compute_f1(7, 2, 3)))],
+        bottom2top_argmax=b2t_ref.argmax(dim=1).tolist())
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f)
+    assert torch.equal(ostc.bottom2top_matrix(t2b), b2t_ref)
+
+    cases = [
+        dict(name="bert_L2", family="bert", L=2, B=4, S=48, St=16, n_best=5, add_l2=True, seg=True, seed=11),
+        dict(name="bert_L12", family="bert", L=12, B=3, S=64, St=16, n_best=5, add_l2=False, seg=True, seed=12),
+        dict(name="bert_L2_noseg", family="bert", L=2, B=4, S=40, St=12, n_best=3, add_l2=True, seg=False, seed=13),
+        dict(name="xlmr_L2", family="xlm-roberta", L=2, B=4, S=48, St=16, n_best=5, add_l2=True, seg=True, seed=14),
+    ]
+    for c in cases:
+        run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns)
+
+
+def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
+    print("== case", c["name"])
+    mk = ncfg.xlmr_base if c["family"] == "xlm-roberta" else ncfg.bert_base
+    cfg = mk(num_hidden_layers=c["L"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = synth.model_state(cfg, labels, seed=c["seed"])
+    batch = synth.nbest_batch(cfg, labels, c["B"], c["S"], n_best=c["n_best"], seed=c["seed"], ragged=True,
+                              trans_len=c["St"])
+    ids, seg = torch.from_numpy(batch["ids"]), torch.from_numpy(batch["seg"])
+    tids, tseg = torch.from_numpy(batch["tids"]), torch.from_numpy(batch["tseg"])
+    y = torch.from_numpy(batch["labels"])
+
+    # ---------------- the reference ----------------
+    enc = hf_encoder(cfg)
+    opt = types.SimpleNamespace(pretrained_model=enc, dropout=0.0, device=torch.device("cpu"), score_util="pp",
+                                sent_repr="bin_sa_cls", cls_type="stc", top2bottom_dict=memory["top2bottom_dict"],
+                                label_vocab_size=labels.n_bottom, pre_trained_model=c["family"],
+                                add_l2_loss=c["add_l2"], add_segment_ids=c["seg"],
+                                class_loss_function=nn.BCELoss(reduction="sum"),
+                                ce_loss_function=nn.NLLLoss(reduction="sum"), mse_loss_function=nn.MSELoss())
+    model = ref_model.make_model(opt)
+    missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+    assert not missing.missing_keys, missing
+    model.train()
+    hs = []
+    hooks = [l.register_forward_hook(lambda m, i, o: hs.append((o[0] if isinstance(o, tuple) else o).detach()))
+             for l in enc.encoder.layer]
+    emb_out = []
+    hooks.append(enc.embeddings.register_forward_hook(lambda m, i, o: emb_out.append(o.detach())))
+    seg_in = seg if c["seg"] else None                       # n_best_asr_bert.py:252 (trans seg NOT nulled, Q4)
+    top, bottoms, final, asr_cls, trans_cls = model(opt, ids, tids, seg_ids=seg_in, trans_seg_ids=tseg,
+                                                    classifier_input_type="asr")
+    for h in hooks:
+        h.remove()
+    L = c["L"]
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        rec, total = ns["cal_total_loss"](top, bottoms, final, y, memory, opt, asr_cls, trans_cls)
+    total.backward()
+    named = list(filter(lambda p: p[1].requires_grad, model.named_parameters()))
+    grads = {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    groups = [dict(params=p, weight_decay=0.0 if any(nd in n for nd in no_decay) else 0.01,
+                   lr=3e-5 if "bert_encoder" in n else 5e-4) for n, p in named]
+    t_total = 40
+    optim = ref_optim.BertAdam(groups, lr=5e-4, warmup=0.1, t_total=t_total)
+    before = {n: p.detach().clone() for n, p in named}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        optim.step()
+        optim.step()          # second step with the same grads: exercises m/v carry-over + schedule step 1
+    after = {n: p.detach().clone() for n, p in named}
+    preds = [ns["pred_one_sample"](i, ts, bottoms, memory, opt) for i, ts in enumerate(top.tolist())]
+
+    # ---------------- the oracle must agree ----------------
+    ocfg = OCfg(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=L,
+                num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                max_position_embeddings=cfg.max_position_embeddings, type_vocab_size=cfg.type_vocab_size,
+                layer_norm_eps=cfg.layer_norm_eps, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                pad_token_id=cfg.pad_token_id, family=cfg.family)
+    om = OracleModel(ocfg, t2b, labels.n_bottom, 0.0)
+    om.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    om.train()
+    otop, obot, ofin, oasr, otr = om(ids, tids, seg_ids=seg_in, trans_seg_ids=tseg)
+    orec, ototal, oparts = ostc.total_loss(otop, obot, ofin, y, t2b, ostc.bottom2top_matrix(t2b), oasr, otr, c["add_l2"])
+    ototal.backward()
+
+    def chk(a, b, tol, what):
+        d = (a - b).abs().max().item()
+        print("   oracle vs reference %-28s max|d| = %.3e" % (what, d))
+        assert d <= tol, (what, d)
+    chk(otop, top, 2e-6, "top_scores")
+    chk(ofin, final, 2e-6, "final_scores")
+    chk(oasr, asr_cls, 2e-5, "asr_cls")
+    chk(otr, trans_cls, 2e-5, "trans_cls")
+    chk(ototal, total, 2e-4 * max(1.0, abs(total.item())), "total_loss")
+    assert abs(orec - rec) < 1e-4 * max(1, abs(rec))
+    for n, p in om.named_parameters():
+        if n in grads:
+            chk(p.grad, grads[n], 2e-5 * max(1.0, grads[n].abs().max().item()), "grad " + n[-40:]) if (
+                n.endswith("word_embeddings.weight") or "layer.0.attention.self.query" in n or n.startswith("clf.top")) else None
+            assert (p.grad - grads[n]).abs().max().item() <= 5e-5 * max(1.0, grads[n].abs().max().item()), n
+        else:
+            assert p.grad is None or p.grad.abs().max() == 0, n
+    oopt = OracleBertAdam(list(om.named_parameters()), lr=5e-4, bert_lr=3e-5, warmup=0.1, t_total=t_total)
+    oopt.step()
+    oopt.step()
+    for n, p in om.named_parameters():
+        d = (p.detach() - after[n]).abs().max().item()
+        assert d <= 2e-7, ("bertadam", n, d)
+    print("   oracle BertAdam (2 steps) matches reference to 2e-7 on all", len(after), "tensors")
+    odec = ostc.decode_indices(otop.detach(), {k: v.detach() for k, v in obot.items()}, t2b, idx2label)
+    for i, pl in enumerate(preds):
+        mine = [idx2label[j] for j in odec[i].tolist() if j >= 0]
+        assert mine == pl, (mine, pl)
+
+    # ---------------- fixture ----------------
+    keep = ["bert_encoder.embeddings.word_embeddings.weight", "bert_encoder.embeddings.position_embeddings.weight",
+            "bert_encoder.embeddings.token_type_embeddings.weight", "bert_encoder.embeddings.LayerNorm.weight",
+            "bert_encoder.encoder.layer.0.attention.self.query.weight", "bert_encoder.encoder.layer.0.attention.self.key.bias",
+            "bert_encoder.encoder.layer.0.attention.self.value.weight",
+            "bert_encoder.encoder.layer.0.attention.output.dense.weight", "bert_encoder.encoder.layer.0.attention.output.LayerNorm.bias",
+            "bert_encoder.encoder.layer.%d.intermediate.dense.weight" % (L - 1), "bert_encoder.encoder.layer.%d.intermediate.dense.bias" % (L - 1),
+            "bert_encoder.encoder.layer.%d.output.dense.weight" % (L - 1), "bert_encoder.encoder.layer.%d.output.LayerNorm.weight" % (L - 1),
+            "clf.top_linear_layer.weight", "clf.top_linear_layer.bias", "clf.linear_layers.lin_2.weight", "clf.linear_layers.lin_25.bias"]
+    fx = dict(meta=np.array(json.dumps(c)), t_total=np.array(t_total),
+              emb_out=emb_out[0][:, :, :32].numpy(), asr_cls=asr_cls.detach().numpy(), trans_cls=trans_cls.detach().numpy(),
+              top=top.detach().numpy(), final=final.detach().numpy(),
+              bottoms=np.concatenate([bottoms["lin_%d" % t].detach().numpy() for t in labels.multi], axis=1),
+              loss_total=np.array(total.item()), loss_record=np.array(rec),
+              decode=ostc.decode_indices(top.detach(), {k: v.detach() for k, v in bottoms.items()}, t2b, idx2label).numpy())
+    for li in range(L):
+        fx["hidden_%d" % li] = hs[li][:, :, :32].numpy()          # first encoder pass (ASR ids): hs[0:L]
+    for n, g in grads.items():
+        fx["gnorm/" + n] = np.array(g.norm().item())
+    for n in keep:
+        g = grads[n]
+        fx["grad/" + n] = g.reshape(-1, g.shape[-1])[:8, :64].numpy() if g.dim() > 1 else g[:64].numpy()
+        d = after[n] - before[n]
+        fx["delta/" + n] = d.reshape(-1, d.shape[-1])[:8, :64].numpy() if d.dim() > 1 else d[:64].numpy()
+    # rows of the word-embedding gradient that are touched (scatter-add parity)
+    used = torch.unique(torch.cat([ids.flatten(), tids.flatten()]))[:16]
+    fx["wordgrad_rows"] = used.numpy()
+    fx["wordgrad_vals"] = grads["bert_encoder.embeddings.word_embeddings.weight"][used, :64].numpy()
+    np.savez_compressed(os.path.join(HERE, "case_%s.npz" % c["name"]), **fx)
+    print("   wrote case_%s.npz  loss=%.6f  preds[0]=%s" % (c["name"], total.item(), preds[0]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""CPU: the oracle (oracle/) reproduces the committed reference outputs (tests/golden/*.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_case, case_inputs
+
+
+def _oracle_run(meta, labels):
+    from oracle.encoder import EncoderConfig
+    from oracle.model import OracleModel
+    from oracle import stc
+    cfg, sd, batch = case_inputs(meta, labels)
+    ocfg = EncoderConfig(**{k: v for k, v in cfg.to_dict().items() if k in EncoderConfig.__dataclass_fields__})
+    m = OracleModel(ocfg, labels.top2bottom, labels.n_bottom, 0.0)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.train()
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    seg = t["seg"] if meta["seg"] else None
+    top, bottoms, final, asr, tr = m(t["ids"], t["tids"], seg_ids=seg, trans_seg_ids=t["tseg"])
+    b2t = stc.bottom2top_matrix(labels.top2bottom)
+    rec, total, parts = stc.total_loss(top, bottoms, final, t["labels"], labels.top2bottom, b2t, asr, tr, meta["add_l2"])
+    total.backward()
+    return m, top, bottoms, final, asr, tr, rec, total
+
+
+@pytest.mark.parametrize("name", ["bert_L2", "bert_L2_noseg", "xlmr_L2"])
+def test_oracle_matches_reference_outputs(name, labels):
+    from oracle import stc
+    from oracle.bertadam import OracleBertAdam
+    meta, z = load_case(name)
+    m, top, bottoms, final, asr, tr, rec, total = _oracle_run(meta, labels)
+    np.testing.assert_allclose(top.detach().numpy(), z["top"], atol=2e-6)
+    np.testing.assert_allclose(final.detach().numpy(), z["final"], atol=2e-6)
+    np.testing.assert_allclose(asr.detach().numpy(), z["asr_cls"], atol=2e-5)
+    np.testing.assert_allclose(tr.detach().numpy(), z["trans_cls"], atol=2e-5)
+    assert abs(total.item() - float(z["loss_total"])) < 2e-4 * abs(float(z["loss_total"]))
+    assert abs(rec - float(z["loss_record"])) < 2e-4 * abs(float(z["loss_record"]))
+    dec = stc.decode_indices(top.detach(), {k: v.detach() for k, v in bottoms.items()}, labels.top2bottom, labels.idx2label)
+    assert np.array_equal(dec.numpy(), z["decode"])          # bit-exact label indices
+    named = dict(m.named_parameters())
+    for key in z.files:
+        if key.startswith("gnorm/"):
+            g = named[key[6:]].grad
+            assert abs(g.norm().item() - float(z[key])) <= 2e-4 * max(1e-3, float(z[key])), key
+        if key.startswith("grad/"):
+            g = named[key[5:]].grad
+            got = g.reshape(-1, g.shape[-1])[:8, :64] if g.dim() > 1 else g[:64]
+            np.testing.assert_allclose(got.numpy(), z[key], atol=5e-5 * max(1.0, float(np.abs(z[key]).max())))
+    before = {n: p.detach().clone() for n, p in named.items()}
+    opt = OracleBertAdam(list(named.items()), lr=5e-4, bert_lr=3e-5, warmup=0.1, t_total=int(z["t_total"]))
+    opt.step(); opt.step()
+    for key in z.files:
+        if key.startswith("delta/"):
+            d = named[key[6:]].detach() - before[key[6:]]
+            got = d.reshape(-1, d.shape[-1])[:8, :64] if d.dim() > 1 else d[:64]
+            np.testing.assert_allclose(got.numpy(), z[key], atol=3e-7)
+
+
+def test_reference_known_answers(labels):
+    from oracle import stc
+    kat = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    k = kat["onehot_to_scalar"]
+    assert stc.class_index(torch.tensor(k["inp"], dtype=torch.float32)).tolist() == k["out"] == [2, 1, 2, 2, 0]
+    for c in kat["update_f1"]:
+        base = (0, 0, 0) if c["pred"] else (2, 3, 4)
+        assert list(stc.update_f1(c["pred"], c["gold"], *base)) == c["out"]
+    for c in kat["compute_f1"]:
+        assert list(stc.compute_f1(*c["inp"])) == pytest.approx(c["out"])
+    assert stc.bottom2top_matrix(labels.top2bottom).argmax(dim=1).tolist() == kat["bottom2top_argmax"]
+    assert labels.bottom2top == kat["bottom2top_argmax"]
+    assert labels.n_bottom == 161 and labels.n_top == 30 and labels.n_head_rows == 171
