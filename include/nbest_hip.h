@@ -1,0 +1,253 @@
+/* nbest_hip.h - C ABI of libnbest_hip.so: the MI355X (gfx950) fine-tuning hot path of
+ * N-Best-ASR-Transformer.
+ *
+ * The reference has NO native / FFI / plugin interface: its only seam is the Python
+ * object injected at /root/reference/models/model.py:19 and called at :43-45,54-56.  This header is
+ * therefore the boundary a maintainer binds from Python with ctypes (INTEGRATION.md shows the stub);
+ * each entry point cites the reference (or third-party) code whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller unless the
+ *     name ends in _host; the library never allocates, never synchronises, never touches the default
+ *     stream: work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - returns NBEST_OK (0) or a negative NBEST_ERR_*; nbest_last_error() gives the message
+ *     (thread-local).  No global mutable state: entry points are re-entrant.
+ *   - dtype: NBEST_F32 or NBEST_BF16 = type of activations, weight matrices and embedding tables.
+ *     Biases, LayerNorm parameters, statistics, losses, gradients of parameters and optimizer state
+ *     are always fp32.
+ *   - matrices are row-major; "M" is the number of token rows B*S.
+ *   - dropout: (p, seed, stream_id) select a counter-based mask that forward and backward
+ *     regenerate identically; p = 0 disables it (parity runs).
+ */
+#ifndef NBEST_HIP_H
+#define NBEST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBEST_ABI_VERSION 1
+
+enum { NBEST_OK = 0, NBEST_ERR_ARG = -1, NBEST_ERR_SHAPE = -2, NBEST_ERR_DTYPE = -3, NBEST_ERR_ALIGN = -4,
+       NBEST_ERR_LAUNCH = -5, NBEST_ERR_WORKSPACE = -6 };
+enum { NBEST_F32 = 0, NBEST_BF16 = 1 };
+
+typedef void* nbest_stream_t; /* hipStream_t */
+
+int nbest_version(void);
+/* copies the calling thread's last error message into buf (NUL-terminated); returns its length */
+int nbest_last_error(char* buf, size_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  embedding gather + LayerNorm (+dropout)
+ * replaces transformers BertEmbeddings / XLMRobertaEmbeddings (installed modeling_bert.py:53-108),
+ * reached from /root/reference/models/model.py:43-45.
+ *   out[m,:] = drop(LN(word[ids[m]] + type[seg[m]] + ptab[pos[m]]))     stats[m] = {mean, rstd}
+ * seg may be NULL (all zeros).  pos is explicit (BERT: arange; XLM-R: pad-offset cumsum).          */
+int nbest_embed_ln_fwd(const int64_t* ids, const int64_t* seg, const int64_t* pos, const void* word,
+                       const void* type, const void* ptab, const float* gamma, const float* beta, void* out,
+                       float* stats, int64_t M, int H, float eps, int dtype, float drop_p, uint64_t seed,
+                       uint32_t drop_stream, nbest_stream_t stream);
+/* backward: LN backward on dout, then scatter-add into the fp32 table gradients (atomics).
+ * Rows word_pad_id of dword and pos_pad_id of dptab receive nothing (nn.Embedding padding_idx;
+ * pass -1 for "no padding row").  dword/dtype_tab/dptab are ACCUMULATED into (+=, the caller
+ * zeroes them); dgamma/dbeta are overwritten unless accumulate.  M = B*S.  ws: >= nbest_embed_bwd_ws_bytes(M, H) bytes.                                                          */
+int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const int64_t* pos, const void* word,
+                       const void* type, const void* ptab, const float* gamma, const float* stats,
+                       const void* dout, float* dword, float* dtype_tab, float* dptab, float* dgamma,
+                       float* dbeta, int B, int S, int H, int n_types, int dtype, int64_t word_pad_id,
+                       int64_t pos_pad_id, int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream,
+                       void* ws, size_t ws_bytes, nbest_stream_t stream);
+size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2/K4/K6  dense GEMM on MFMA with fused epilogues
+ * replaces nn.Linear inside BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput
+ * (installed modeling_bert.py:154-177, 282-293, 325-351) and their autograd backward.
+ *   C[M,N] = epi( op(A)[M,K] . op(B)[K,N] )
+ *   trans_a = 0: A stored [M][K] (lda)          trans_a = 1: A stored [K][M]
+ *   trans_b = 0: B stored [N][K] (torch Linear)  trans_b = 1: B stored [K][N]
+ * N must be a multiple of 128, K of 64 unless trans_a (then K is free: token dimension); lda/ldb/ldc
+ * multiples of 8 elements; pointers 16-byte aligned.                                                */
+enum {
+  NBEST_EPI_NONE = 0,          /* C = acc                                                    */
+  NBEST_EPI_BIAS = 1,          /* C = acc + bias[n]                                          */
+  NBEST_EPI_BIAS_GELU = 2,     /* U = acc + bias[n] ; C = gelu_erf(U)      (U and C stored)  */
+  NBEST_EPI_BIAS_DROP_RES = 3, /* C = drop(acc + bias[n]) + R[m,n]                           */
+  NBEST_EPI_DGELU = 4,         /* C = acc * gelu'(U[m,n])                                    */
+  NBEST_EPI_RES = 5,           /* C = acc + R[m,n]                                           */
+  NBEST_EPI_F32_SPLITK = 6     /* Cf32[N x ...] = sum over K-splits (weight gradient), fp32  */
+};
+typedef struct nbest_gemm_args {
+  const void* A;
+  const void* B;
+  void* C;            /* dtype output (or fp32 when epilogue == NBEST_EPI_F32_SPLITK)          */
+  const float* bias;  /* [N] or NULL                                                          */
+  const void* R;      /* residual [M][ldr], dtype                                             */
+  void* U;            /* pre-activation [M][ldu], dtype: written by BIAS_GELU, read by DGELU   */
+  void* ws;           /* split-K slabs: >= nbest_gemm_ws_bytes(args)                           */
+  size_t ws_bytes;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc, ldr, ldu;
+  int32_t trans_a, trans_b;
+  int32_t epilogue;
+  int32_t dtype;
+  int32_t accumulate; /* F32_SPLITK only: C += result instead of C = result                    */
+  float drop_p;
+  uint32_t drop_stream;
+  uint64_t seed;
+} nbest_gemm_args;
+size_t nbest_gemm_ws_bytes(const nbest_gemm_args* a);
+int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  scaled-dot-product attention with a per-sample key-padding mask
+ * replaces eager_attention_forward (installed modeling_bert.py:111-136); mask rule of
+ * /root/reference/models/model.py:43 is applied by the CALLER (key_mask = ids > 0, uint8 [B,S]).
+ *   qkv [M][3H] (Q | K | V, head h = columns h*d .. h*d+d of each third), ctx [M][H],
+ *   lse [B][heads][S] = log-sum-exp of the scaled masked scores (saved for backward).
+ *   P = softmax(Q K^T / sqrt(d) + (mask ? 0 : -inf)) ; ctx = drop(P) V.  d must be 64; S <= 512
+ *   (bf16: S <= 256).                                                                              */
+int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S,
+                        int heads, int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream,
+                        nbest_stream_t stream);
+/* dqkv [M][3H] receives dQ | dK | dV (overwritten, no accumulation).                                */
+int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx,
+                        const float* lse, void* dqkv, int B, int S, int heads, int d, int dtype,
+                        float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  LayerNorm over the hidden dimension (BertSelfOutput / BertOutput LayerNorm,
+ * installed modeling_bert.py:282-293, 340-351).  stats[m] = {mean, rstd} fp32.                      */
+int nbest_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                        int64_t M, int H, float eps, int dtype, nbest_stream_t stream);
+/* dx = LN'(dy); dgamma = sum_m dy*xhat; dbeta = sum_m dy (+= when accumulate).
+ * The LayerNorm input was x = drop(dense_out) + residual, so two gradients leave this kernel:
+ *   dx      - gradient of the residual branch (unmasked), and
+ *   dx_drop - gradient of dense_out = dropout mask (regenerated from seed/drop_stream) applied to dx;
+ *             only written when drop_p > 0 (otherwise the caller uses dx for both; dx_drop may be NULL).
+ * dbias != NULL: dbias = sum_m dx_drop (gradient of the dense layer's bias).
+ * ws: >= nbest_rowred_ws_bytes(M, H).                                                               */
+int nbest_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                        void* dx_drop, float* dgamma, float* dbeta, float* dbias, int64_t M, int H, int dtype,
+                        int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
+                        size_t ws_bytes, nbest_stream_t stream);
+size_t nbest_rowred_ws_bytes(int64_t M, int64_t N);
+/* out[n] (+)= sum_m X[m][n]   (bias gradients).  ws: >= nbest_rowred_ws_bytes(M, N).               */
+int nbest_colsum(const void* X, float* out, int64_t M, int64_t N, int64_t ld, int dtype, int accumulate,
+                 void* ws, size_t ws_bytes, nbest_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  STC heads + losses, forward and analytic backward in one call
+ * replaces HierarchicalClassifier.forward (/root/reference/models/modules/hierarchical_classifier.py:35-60),
+ * cal_total_loss / cal_ce_loss (/root/reference/n_best_asr_bert.py:145-195), convert_labels and
+ * onehot_to_scalar (/root/reference/utils/STC_util.py:4-7,29-51).
+ * Label space: n_top top labels; bottom_of[...] lists, for top t, its bottom ids
+ * bottom_ids[bottom_off[t] .. bottom_off[t+1]); tops with >= 2 bottoms own a softmax head whose rows
+ * in the concatenated head matrix Wh [R][H] start at head_row[t] (single-bottom tops: -1); rows
+ * 0..n_top-1 of Wh are the top (sigmoid) classifier.  R = n_top + sum of multi-value head sizes.
+ *   cls     = hidden[b * cls_stride .. +H]  (raw CLS row, models/model.py:46-47), dtype
+ *   top     [B][n_top], bott [B][R - n_top] (softmax heads concatenated in head order), final [B][n_bottom]
+ *   loss_parts[4] = {BCE_sum(final,y), BCE_sum(top, y.B2T), mean_k NLL_sum_k, 0}  (fp32, overwritten)
+ *   dcls [B][H] fp32 = d(sum of the three)/d cls ; dWh [R][H], dbh [R] fp32 (overwritten unless accumulate)
+ * feature dropout: an independent mask per linear layer (hierarchical_classifier.py:41,46).
+ * ws: >= nbest_heads_ws_bytes(B, R, H).                                                             */
+typedef struct nbest_label_space {
+  int32_t n_top, n_bottom, n_rows;
+  const int32_t* bottom_off; /* [n_top+1] device */
+  const int32_t* bottom_ids; /* [n_bottom] device */
+  const int32_t* head_row;   /* [n_top] device   */
+} nbest_label_space;
+size_t nbest_heads_ws_bytes(int B, int R, int H);
+int nbest_stc_heads(const void* hidden, int64_t cls_stride, const float* Wh, const float* bh,
+                    const nbest_label_space* ls, const float* labels, float* top, float* bott, float* final_scores,
+                    float* loss_parts, float* dcls, float* dWh, float* dbh, int B, int H, int dtype,
+                    int need_grad, int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
+                    size_t ws_bytes, nbest_stream_t stream);
+
+/* K8  pooled-CLS MSE auxiliary loss (--add_l2_loss): nn.MSELoss() between the ASR and transcript CLS
+ * rows, /root/reference/n_best_asr_bert.py:166-170,574.  loss[0] = mean((a-t)^2);
+ * da += grad_scale * 2(a-t)/(B*H); dt = -grad_scale * 2(a-t)/(B*H)  (the transcript branch is NOT detached). */
+int nbest_cls_mse(const void* hidden_a, int64_t stride_a, const void* hidden_t, int64_t stride_t, float* loss,
+                  float* da, float* dt, int B, int H, int dtype, float grad_scale, nbest_stream_t stream);
+
+/* scatter a [B][H] fp32 CLS gradient into row 0 of every sequence of dhidden [B*S][H] (all other
+ * rows zero): the backward of sequence_output[:, 0, :].                                             */
+int nbest_cls_grad_scatter(const float* dcls, void* dhidden, int B, int S, int H, int dtype,
+                           nbest_stream_t stream);
+
+/* K10 device decode of pred_one_sample (/root/reference/n_best_asr_bert.py:198-215):
+ * pred[b][t] = predicted bottom label index when top[b][t] > 0.5 (strict), else -1; for a
+ * multi-value top the argmax of its head (first maximum), -1 when none_flag[that bottom] != 0.      */
+int nbest_stc_decode(const float* top, const float* bott, const nbest_label_space* ls,
+                     const uint8_t* none_flag, int32_t* pred, int B, nbest_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K9  multi-tensor BertAdam over flat arenas
+ * replaces BertAdam.step (/root/reference/models/optimization.py:237-302) with the per-parameter
+ * grouping of /root/reference/n_best_asr_bert.py:540-561: per tensor g *= min(1, 1/(||g||+1e-6));
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; u = m/(sqrt(v)+eps) [+ wd p]; p -= lr*lr_mult * u,
+ * lr_mult = warmup-linear schedule value for this step (optimization.py:162-171; one scalar: every
+ * tensor that receives gradients shares the same step count).
+ * The arenas p, g, m, v are fp32; tensors are described by device descriptors ordered by offset.
+ * block_start[t] = sum_{u<t} ceil(numel[u] / nbest_bertadam_chunk()); n_blocks = that sum over all
+ * tensors.  If p_lowp != NULL the updated parameters are also written as bf16 at the same element
+ * offsets (the compute copy the GEMMs read).  ws: >= (n_blocks + n_tensors) floats.                 */
+typedef struct nbest_tensor_desc {
+  int64_t offset;
+  int64_t numel;
+  float lr;            /* base learning rate of the tensor (bert_lr / lr) */
+  float wd;            /* 0.01, or 0 for bias / LayerNorm */
+  int32_t active;      /* 0: no gradient this step (skipped, like `p.grad is None`) */
+  int32_t block_start;
+} nbest_tensor_desc;
+int nbest_bertadam_chunk(void);
+int nbest_bertadam_step(float* p, float* g, float* m, float* v, void* p_lowp, const nbest_tensor_desc* descs,
+                        int n_tensors, int n_blocks, float lr_mult, float b1, float b2, float eps,
+                        float max_grad_norm, void* ws, size_t ws_bytes, nbest_stream_t stream);
+/* fp32 -> bf16 copy of an arena (initial compute copy / after loading a checkpoint) */
+int nbest_cast_f32_to_bf16(const float* src, void* dst, int64_t n, nbest_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The whole encoder stack in one call (launch-overhead-free path used by training):
+ * embeddings -> L x {QKV GEMM, attention, out-proj+residual, LN, FFN-up+GELU, FFN-down+residual, LN}.
+ * Replaces the encoder(...) calls at /root/reference/models/model.py:43-45,54-56 and autograd
+ * through them (/root/reference/n_best_asr_bert.py:264).
+ * Parameter arenas: `wts` = matrices/tables in `dtype`, `prm` = the fp32 master arena (biases,
+ * LayerNorm), `grad` = fp32 gradient arena; all three share ONE element-offset table
+ * (nbest_encoder_layout).  act: activation stash written by forward, consumed by backward,
+ * >= nbest_encoder_act_bytes(); ws: scratch >= nbest_encoder_ws_bytes().                            */
+typedef struct nbest_layer_offsets {
+  int64_t wqkv, bqkv, wo, bo, ln1_g, ln1_b, w1, b1, w2, b2, ln2_g, ln2_b;
+} nbest_layer_offsets;
+typedef struct nbest_encoder_desc {
+  int32_t dtype, B, S, H, L, heads, F;
+  int32_t vocab, max_pos, n_types;
+  float ln_eps, hidden_drop, attn_drop;
+  int64_t word_pad_id, pos_pad_id; /* padding_idx rows (no gradient), -1 = none */
+  int64_t off_word, off_pos, off_type, off_emb_ln_g, off_emb_ln_b;
+  const nbest_layer_offsets* layers_host; /* [L], HOST memory */
+  uint64_t seed;
+  uint32_t drop_stream_base; /* distinct per encoder pass within a step */
+  int32_t pad;
+} nbest_encoder_desc;
+size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
+size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);
+/* hidden_out: pointer to the final hidden states [M][H] inside act (returned through *hidden_out) */
+int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wts, const float* prm, const int64_t* ids,
+                          const int64_t* seg, const int64_t* pos, const uint8_t* key_mask, void* act,
+                          size_t act_bytes, void* ws, size_t ws_bytes, void** hidden_out, nbest_stream_t stream);
+/* dhidden [M][H] (dtype) is consumed (overwritten).  Parameter gradients are written into `grad`
+ * (overwritten; accumulate != 0: added).                                                            */
+int nbest_encoder_backward(const nbest_encoder_desc* d, const void* wts, const float* prm, float* grad,
+                           const int64_t* ids, const int64_t* seg, const int64_t* pos, const uint8_t* key_mask,
+                           void* act, size_t act_bytes, void* dhidden, void* ws, size_t ws_bytes, int accumulate,
+                           nbest_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBEST_HIP_H */

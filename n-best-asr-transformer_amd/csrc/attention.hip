@@ -1,0 +1,491 @@
+// K3 / K3b: scaled-dot-product attention with a per-sample key-padding mask, forward and backward.
+//
+// bf16 path (production): one workgroup (4 waves) per (sample, head); the whole K and V of a head
+// live in LDS (S <= 256, d = 64: 2 x 32 KiB), filled by LDS-DMA (buffer_load ... lds) straight from the
+// fused qkv activation [M][3H] - the sequence's own buffer descriptor zero-fills rows past S.
+//   forward : wave = 32 query rows.  scores are computed SWAPPED, S^T = K . Q^T with
+//             v_mfma_f32_32x32x16_bf16, so a lane owns ONE query row (half of its keys; the other
+//             half sits in lane^32): softmax max/sum are in-lane reductions + one wave shuffle.
+//             The probability tile never leaves registers: the fp32 accumulator tile, converted to
+//             bf16, IS the A operand of the P.V MFMA (k order permuted; V is fetched with the
+//             matching permuted transposed LDS read ds_read_b64_tr_b16).
+//   backward: wave = 32 keys ("key on the lane"): S = Q.K^T and dP = dO.V^T tiles are recomputed per
+//             32-query block from the saved log-sum-exp; dV += P^T dO and dK += dS^T Q use the
+//             accumulator-as-operand trick again (no LDS round trip, no atomics, no cross-wave sums);
+//             only dS crosses LDS once, for dQ = dS . K.
+//   LDS image of every [rows][64] bf16 tile: 128-byte rows, 16-byte chunk index XORed with
+//             g(row) = ((row>>2)&3) | (((row>>1)&1)<<2): conflict-free for the ds_read_b128 row reads
+//             of the 32x32x16 operand AND for the 4-row transposed reads.
+// fp32 path (parity/debug): one thread per query row, plain VALU math, any S <= 512.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int crow(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+__device__ __forceinline__ int gsw(int row) { return ((row >> 2) & 3) | (((row >> 1) & 1) << 2); }
+
+// =================================================================================================
+// fp32 reference-grade kernels
+// =================================================================================================
+__global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                           float* __restrict__ ctx, float* __restrict__ lse, int S, int heads,
+                                                           int H, float scale, DropCfg drop) {
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int i = blockIdx.y * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  const int64_t ld = 3 * (int64_t)H;
+  const float* base = qkv + (int64_t)b * S * ld;
+  const float* qp = base + i * ld + h * 64;
+  float q[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) q[d] = qp[d];
+  float mx = -INFINITY, l = 0.f;
+  for (int j = 0; j < S; ++j) {
+    if (!mask[b * S + j]) continue;
+    const float* kp = base + j * ld + H + h * 64;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) s = fmaf(q[d], kp[d], s);
+    s *= scale;
+    const float nm = fmaxf(mx, s);
+    l = l * expf(mx - nm) + expf(s - nm);
+    mx = nm;
+  }
+  const float lse_i = mx + logf(l);
+  float o[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) o[d] = 0.f;
+  for (int j = 0; j < S; ++j) {
+    if (!mask[b * S + j]) continue;
+    const float* kp = base + j * ld + H + h * 64;
+    const float* vp = base + j * ld + 2 * H + h * 64;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) s = fmaf(q[d], kp[d], s);
+    float p = expf(s * scale - lse_i);
+    if (drop.thr16) p = nb_keep(drop, (uint32_t)((bh * S + i) * S + j)) ? p * drop.scale : 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) o[d] = fmaf(p, vp[d], o[d]);
+  }
+  float* op = ctx + ((int64_t)b * S + i) * H + h * 64;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) op[d] = o[d];
+  lse[(int64_t)bh * S + i] = lse_i;
+}
+
+// dqkv must be zeroed before the launch (dK / dV are accumulated with atomics)
+__global__ __launch_bounds__(128) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                           const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                           const float* __restrict__ lse, float* __restrict__ dqkv, int S,
+                                                           int heads, int H, float scale, DropCfg drop) {
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int i = blockIdx.y * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  const int64_t ld = 3 * (int64_t)H;
+  const float* base = qkv + (int64_t)b * S * ld;
+  float* dbase = dqkv + (int64_t)b * S * ld;
+  const float* qp = base + i * ld + h * 64;
+  const float* dop = dctx + ((int64_t)b * S + i) * H + h * 64;
+  const float* op = ctx + ((int64_t)b * S + i) * H + h * 64;
+  float q[64], dO[64], dq[64];
+  float delta = 0.f;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) { q[d] = qp[d]; dO[d] = dop[d]; dq[d] = 0.f; delta = fmaf(dO[d], op[d], delta); }
+  const float lse_i = lse[(int64_t)bh * S + i];
+  for (int j = 0; j < S; ++j) {
+    if (!mask[b * S + j]) continue;
+    const float* kp = base + j * ld + H + h * 64;
+    const float* vp = base + j * ld + 2 * H + h * 64;
+    float s = 0.f, dpt = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) { s = fmaf(q[d], kp[d], s); dpt = fmaf(dO[d], vp[d], dpt); }
+    const float p = expf(s * scale - lse_i);
+    float pt = p, dp = dpt;
+    if (drop.thr16) {
+      const bool keep = nb_keep(drop, (uint32_t)((bh * S + i) * S + j));
+      pt = keep ? p * drop.scale : 0.f;
+      dp = keep ? dpt * drop.scale : 0.f;
+    }
+    const float ds = p * (dp - delta) * scale;
+    float* dkp = dbase + j * ld + H + h * 64;
+    float* dvp = dbase + j * ld + 2 * H + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+      dq[d] = fmaf(ds, kp[d], dq[d]);
+      atomicAdd(dkp + d, ds * q[d]);
+      atomicAdd(dvp + d, pt * dO[d]);
+    }
+  }
+  float* dqp = dbase + i * ld + h * 64;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) dqp[d] = dq[d];
+}
+
+// =================================================================================================
+// bf16 MFMA kernels
+// =================================================================================================
+// LDS-DMA a [Sp rows][64] bf16 tile (rows = tokens of one sequence, 64 columns starting at col_off)
+__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rs, char* tile, int Sp, int col_off, int ld, int tid) {
+  const int wave = tid >> 6;
+  const int iters = Sp >> 5;  // Sp*8 chunks / 256 threads
+  for (int i = 0; i < iters; ++i) {
+    const int p = i * 256 + tid;
+    const int row = p >> 3, slot = p & 7;
+    const int c = slot ^ gsw(row);
+    const uint32_t voff = (uint32_t)((row * ld + col_off + c * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * 256 + wave * 64) * 16), 16, voff, 0, 0, 0);
+  }
+}
+
+// ds_read_b128 row fragment of the 32x32x16 operand: lane l -> row (row0 + l&31), k = 16*ks + 8*(l>>5) + j
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int ks, int lane) {
+  const int row = row0 + (lane & 31);
+  const int c = 2 * ks + (lane >> 5);
+  return *(const bf16x8*)(tile + row * 128 + ((c ^ gsw(row)) << 4));
+}
+
+// transposed (k-strided) fragment of the 32x32x16 B operand out of a [rows=k][64] tile:
+// lane l -> column col0 + (l&31); PERMUTED = k order of an accumulator tile used as the A operand
+// (element j of lane half hh is k = kbase + 8*(j>>2) + 4*hh + (j&3)); natural: k = kbase + 8*hh + j.
+template <bool PERMUTED>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0, int lane) {
+  const int g4 = lane >> 4, hh = g4 >> 1, i = lane & 15, qq = i >> 2, pq = i & 3;
+  const int col = col0 + 16 * (g4 & 1) + 4 * pq;
+  const int r1 = kbase + (PERMUTED ? 4 * hh : 8 * hh) + qq;
+  const int r2 = r1 + (PERMUTED ? 8 : 4);
+  const char* a1 = tile + r1 * 128 + (((col >> 3) ^ gsw(r1)) << 4) + ((col & 4) ? 8 : 0);
+  const char* a2 = tile + r2 * 128 + (((col >> 3) ^ gsw(r2)) << 4) + ((col & 4) ? 8 : 0);
+  const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a1);
+  const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a2);
+  bf16x8 o;
+  o[0] = v1[0]; o[1] = v1[1]; o[2] = v1[2]; o[3] = v1[3]; o[4] = v2[0]; o[5] = v2[1]; o[6] = v2[2]; o[7] = v2[3];
+  return o;
+}
+
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)a[8 * s + j];
+  return o;
+}
+
+// write a wave's [32][64] fp32 accumulator pair (columns 0-31 / 32-63; lane = column) into rows
+// row0.. of a plain [rows][64] bf16 LDS image, then store those 32 rows with 16-byte accesses.
+__device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0, const f32x16& o1, int lane, bf16* gbase,
+                                           int64_t gld, int rows_valid) {
+  const int hh = lane >> 5, c = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    char* rowp = img + (row0 + crow(r, hh)) * 128;
+    *(bf16*)(rowp + c * 2) = (bf16)o0[r];
+    *(bf16*)(rowp + 64 + c * 2) = (bf16)o1[r];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = i * 64 + lane, row = p >> 3, ch = p & 7;
+    if (row < rows_valid) *(i32x4*)(gbase + (int64_t)row * gld + ch * 8) = *(const i32x4*)(img + (row0 + row) * 128 + ch * 16);
+  }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                            bf16* __restrict__ ctx, float* __restrict__ lse, int S, int heads,
+                                                            int H, float scale, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int Sp = NKB * 32;
+  char* Kt = lds;
+  char* Vt = lds + Sp * 128;
+  float* madd = (float*)(lds + 2 * Sp * 128);
+  char* Ost = lds + 2 * Sp * 128 + Sp * 4;  // 4 x 4 KiB, one [32][64] image per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int ld = 3 * H;
+  const bf16* base = qkv + (int64_t)b * S * ld;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(S * ld * 2), 0x00020000);
+  stage_rows(rs, Kt, Sp, H + h * 64, ld, tid);
+  stage_rows(rs, Vt, Sp, 2 * H + h * 64, ld, tid);
+  for (int k = tid; k < Sp; k += 256) madd[k] = (k < S && mask[b * S + k]) ? 0.f : -INFINITY;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int qb = wave; qb < NKB; qb += 4) {
+    const int q0 = 32 * qb, qrow = q0 + (lane & 31);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const i32x4 raw = (qrow < S) ? *(const i32x4*)(base + (int64_t)qrow * ld + h * 64 + 16 * ks + 8 * hh) : i32x4{0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8, raw);
+    }
+    f32x16 sc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, 32 * kb, ks, lane), qf[ks], a, 0, 0, 0);
+      sc[kb] = a;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 ma = *(const f32x4*)(madd + 32 * kb + 8 * r4 + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = sc[kb][4 * r4 + e] * scale + ma[e];
+          sc[kb][4 * r4 + e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = (mx == -INFINITY) ? 0.f : mx;
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __expf(sc[kb][r] - mxs);
+        sc[kb][r] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (hh == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = mxs + __logf(sum);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = sc[kb][r] * inv;
+        if (drop.thr16) {
+          const int key = 32 * kb + crow(r, hh);
+          pv = nb_keep(drop, (uint32_t)((bh * S + qrow) * S + key)) ? pv * drop.scale : 0.f;
+        }
+        sc[kb][r] = pv;
+      }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pa = acc_to_frag(sc[kb], s);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 0, lane), o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 32, lane), o1, 0, 0, 0);
+      }
+    store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0);
+  }
+}
+
+// backward, Sp = 32*NKB <= 128.  LDS: Qt | Kt | Vt | dOt ([Sp][64] bf16 each) | dSb [Sp][128] bf16 | lse | delta | madd
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                            const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+                                                            const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
+                                                            int heads, int H, float scale, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int Sp = NKB * 32;
+  char* Qt = lds;
+  char* Kt = Qt + Sp * 128;
+  char* Vt = Kt + Sp * 128;
+  char* dOt = Vt + Sp * 128;
+  char* dSb = dOt + Sp * 128;                    // [Sp][256 B], chunk ^= row & 15
+  float* lse_s = (float*)(dSb + Sp * 256);
+  float* del_s = lse_s + Sp;
+  float* madd = del_s + Sp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int ld = 3 * H;
+  const bf16* base = qkv + (int64_t)b * S * ld;
+  const bf16* dobase = dctx + (int64_t)b * S * H;
+  const bf16* obase = ctx + (int64_t)b * S * H;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(S * ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, (uint32_t)(S * H * 2), 0x00020000);
+  stage_rows(rs, Qt, Sp, h * 64, ld, tid);
+  stage_rows(rs, Kt, Sp, H + h * 64, ld, tid);
+  stage_rows(rs, Vt, Sp, 2 * H + h * 64, ld, tid);
+  stage_rows(rsd, dOt, Sp, h * 64, H, tid);
+  for (int k = tid; k < Sp; k += 256) {
+    madd[k] = (k < S && mask[b * S + k]) ? 0.f : -INFINITY;
+    lse_s[k] = (k < S) ? lse[(int64_t)bh * S + k] : INFINITY;
+  }
+  {  // delta[q] = sum_d dO[q][d] * O[q][d]; two threads per row (Sp <= 128 -> 256 threads cover it)
+    const int r = tid >> 1, half = tid & 1;
+    float s = 0.f;
+    if (r < S) {
+      const bf16* dp = dobase + (int64_t)r * H + h * 64 + 32 * half;
+      const bf16* op = obase + (int64_t)r * H + h * 64 + 32 * half;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a[8], o[8];
+        Vec8<bf16>::load(dp + 8 * c, a);
+        Vec8<bf16>::load(op + 8 * c, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(a[j], o[j], s);
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    if (half == 0 && r < Sp) del_s[r] = s;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dk0[r] = dk1[r] = dv0[r] = dv1[r] = 0.f;
+  if (wave < NKB) {
+    const int key = 32 * wave + (lane & 31);
+    const float mk = madd[key];
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = row_frag(Kt, 32 * wave, ks, lane);
+      vf[ks] = row_frag(Vt, 32 * wave, ks, lane);
+    }
+#pragma unroll 1
+    for (int qb = 0; qb < NKB; ++qb) {
+      f32x16 sa, da;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = da[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, 32 * qb, ks, lane), kf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOt, 32 * qb, ks, lane), vf[ks], da, 0, 0, 0);
+      }
+      // sa/da: lane holds [q = 32qb + crow(r,hh)][key]
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 l4 = *(const f32x4*)(lse_s + 32 * qb + 8 * r4 + 4 * hh);
+        const f32x4 d4 = *(const f32x4*)(del_s + 32 * qb + 8 * r4 + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * r4 + e;
+          const int q = 32 * qb + 8 * r4 + 4 * hh + e;
+          const float p = __expf(sa[r] * scale + mk - l4[e]);
+          float pt = p, dp = da[r];
+          if (drop.thr16) {
+            const bool keep = nb_keep(drop, (uint32_t)((bh * S + q) * S + key));
+            pt = keep ? p * drop.scale : 0.f;
+            dp = keep ? dp * drop.scale : 0.f;
+          }
+          const float ds = p * (dp - d4[e]) * scale;
+          sa[r] = pt;   // P~  (-> dV)
+          da[r] = ds;   // dS' (-> dK, dQ)
+          *(bf16*)(dSb + q * 256 + ((((key >> 3) ^ (q & 15))) << 4) + (key & 7) * 2) = (bf16)ds;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pa = acc_to_frag(sa, s), dsa = acc_to_frag(da, s);
+        const bf16x8 do0 = tr_frag<true>(dOt, 32 * qb + 16 * s, 0, lane), do1 = tr_frag<true>(dOt, 32 * qb + 16 * s, 32, lane);
+        const bf16x8 q0f = tr_frag<true>(Qt, 32 * qb + 16 * s, 0, lane), q1f = tr_frag<true>(Qt, 32 * qb + 16 * s, 32, lane);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, do0, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, do1, dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, q0f, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, q1f, dk1, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();  // dSb complete
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq0[r] = dq1[r] = 0.f;
+  if (wave < NKB) {
+#pragma unroll
+    for (int ks = 0; ks < 2 * NKB; ++ks) {
+      const int row = 32 * wave + (lane & 31);
+      const int c = 2 * ks + hh;
+      const bf16x8 dsf = *(const bf16x8*)(dSb + row * 256 + ((c ^ (row & 15)) << 4));
+      dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 0, lane), dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 32, lane), dq1, 0, 0, 0);
+    }
+  }
+  __syncthreads();  // everyone is done reading Qt / Kt / Vt: reuse them as output images
+  if (wave < NKB) {
+    const int r0 = 32 * wave;
+    bf16* g = dqkv + ((int64_t)b * S + r0) * ld + h * 64;
+    store_tile(Qt, r0, dq0, dq1, lane, g, ld, S - r0);
+    store_tile(Kt, r0, dk0, dk1, lane, g + H, ld, S - r0);
+    store_tile(Vt, r0, dv0, dv1, lane, g + 2 * H, ld, S - r0);
+  }
+}
+
+static size_t fwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * 256 + (size_t)nkb * 32 * 4 + 4 * 4096; }
+static size_t bwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * (4 * 128 + 256) + (size_t)nkb * 32 * 12; }
+
+template <int NKB>
+static void launch_fwd(const bf16* qkv, const uint8_t* mask, bf16* ctx, float* lse, int B, int S, int heads, int H, float scale,
+                       DropCfg d, hipStream_t st) {
+  const size_t sm = fwd_lds_bytes(NKB);
+  (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  attn_fwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d);
+}
+template <int NKB>
+static void launch_bwd(const bf16* qkv, const uint8_t* mask, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv, int B,
+                       int S, int heads, int H, float scale, DropCfg d, hipStream_t st) {
+  const size_t sm = bwd_lds_bytes(NKB);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  attn_bwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, S, heads, H, scale, d);
+}
+
+static int check_common(const char* who, int B, int S, int heads, int d, int dtype) {
+  NB_CHECK(B > 0 && S > 0 && heads > 0, NBEST_ERR_SHAPE, "%s: bad shape", who);
+  NB_CHECK(d == 64, NBEST_ERR_SHAPE, "%s: head dimension %d not supported (64 only)", who, d);
+  NB_CHECK(dtype == NBEST_F32 || dtype == NBEST_BF16, NBEST_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
+  NB_CHECK((int64_t)B * heads * S * S < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "%s: B*heads*S*S overflows the dropout counter", who);
+  return NBEST_OK;
+}
+
+}  // namespace
+
+extern "C" int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
+                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
+  NB_CHECK(qkv && key_mask && ctx && lse, NBEST_ERR_ARG, "attention_fwd: null pointer");
+  if (int e = check_common("attention_fwd", B, S, heads, d, dtype)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const int H = heads * d;
+  const float scale = 1.0f / sqrtf((float)d);
+  const DropCfg dc = make_drop(drop_p, seed, drop_stream);
+  if (dtype == NBEST_F32) {
+    NB_CHECK(S <= 512, NBEST_ERR_SHAPE, "attention_fwd(f32): S=%d > 512", S);
+    attn_fwd_f32_kernel<<<dim3(B * heads, (S + 127) / 128), 128, 0, st>>>((const float*)qkv, key_mask, (float*)ctx, lse, S, heads, H, scale, dc);
+  } else {
+    NB_CHECK(S <= 256, NBEST_ERR_SHAPE, "attention_fwd(bf16): S=%d > 256", S);
+    NB_CHECK((int64_t)S * 3 * H * 2 < ((int64_t)1 << 31), NBEST_ERR_SHAPE, "attention_fwd: sequence too large");
+    const int nkb = (S + 31) / 32;
+#define F(N) case N: launch_fwd<N>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, S, heads, H, scale, dc, st); break;
+    switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
+#undef F
+  }
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
+                                   void* dqkv, int B, int S, int heads, int d, int dtype, float drop_p, uint64_t seed,
+                                   uint32_t drop_stream, nbest_stream_t stream) {
+  NB_CHECK(qkv && key_mask && ctx && dctx && lse && dqkv, NBEST_ERR_ARG, "attention_bwd: null pointer");
+  if (int e = check_common("attention_bwd", B, S, heads, d, dtype)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const int H = heads * d;
+  const float scale = 1.0f / sqrtf((float)d);
+  const DropCfg dc = make_drop(drop_p, seed, drop_stream);
+  if (dtype == NBEST_F32) {
+    NB_CHECK(S <= 512, NBEST_ERR_SHAPE, "attention_bwd(f32): S=%d > 512", S);
+    hipError_t e = hipMemsetAsync(dqkv, 0, (size_t)B * S * 3 * H * sizeof(float), st);
+    NB_CHECK(e == hipSuccess, NBEST_ERR_LAUNCH, "attention_bwd: memset failed: %s", hipGetErrorString(e));
+    attn_bwd_f32_kernel<<<dim3(B * heads, (S + 127) / 128), 128, 0, st>>>((const float*)qkv, key_mask, (const float*)ctx,
+                                                                          (const float*)dctx, lse, (float*)dqkv, S, heads, H, scale, dc);
+  } else {
+    NB_CHECK(S <= 128, NBEST_ERR_SHAPE, "attention_bwd(bf16): S=%d > 128 is not built yet", S);
+    const int nkb = (S + 31) / 32;
+#define F(N) case N: launch_bwd<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, B, S, heads, H, scale, dc, st); break;
+    switch (nkb) { F(1) F(2) F(3) F(4) }
+#undef F
+  }
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}

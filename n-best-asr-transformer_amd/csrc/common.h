@@ -1,0 +1,165 @@
+// Shared device/host helpers for libnbest_hip.so (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/nbest_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+#define LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void nbest_set_error(const char* fmt, ...);
+#define NB_CHECK(cond, code, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      nbest_set_error(__VA_ARGS__);          \
+      return (code);                         \
+    }                                        \
+  } while (0)
+#define NB_LAUNCH_CHECK()                                                       \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      nbest_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,            \
+                      hipGetErrorString(e__));                                  \
+      return NBEST_ERR_LAUNCH;                                                  \
+    }                                                                           \
+  } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- scalar conversions ----------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+// 4-element vector load/store of T as float4 (16 B for fp32, 8 B for bf16)
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Vec4<bf16> {
+  static __device__ __forceinline__ f32x4 load(const bf16* p) {
+    bf16x4 v = *(const bf16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+    *(bf16x4*)p = o;
+  }
+};
+// 8-element vector load/store of T as 2 x float4
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float* o) {
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  }
+  static __device__ __forceinline__ void store(float* p, const float* v) {
+    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+};
+template <> struct Vec8<bf16> {
+  static __device__ __forceinline__ void load(const bf16* p, float* o) {
+    bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ void store(bf16* p, const float* v) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+    *(bf16x8*)p = o;
+  }
+};
+
+// ---- wave64 / block reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); smem needs >= 16 floats. All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += smem[i];
+  return r;
+}
+
+// ---- GELU (erf form, as the reference's encoder: hidden_act="gelu") ----------------------------
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float u) {
+  // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
+
+// ---- counter-based dropout ---------------------------------------------------------------------
+// keep-decision for element `idx` of stream `stream` under (seed): 16-bit uniform compared with a
+// 16-bit threshold.  thr16 = round(p * 65536); the effective drop probability is thr16/65536 and
+// the survivor scale is 65536/(65536-thr16) (computed on the host, passed as `scale`).
+// One 32-bit hash yields the decisions of the element PAIR (idx & ~1, idx | 1).
+__device__ __forceinline__ uint32_t nb_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropCfg {
+  uint32_t thr16;   // 0 => dropout disabled
+  float scale;      // 1/(1-p_eff)
+  uint32_t key;     // hash(seed, stream)
+};
+__host__ __device__ __forceinline__ uint32_t nb_mix_key(uint64_t seed, uint32_t stream) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(stream + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return (uint32_t)(z ^ (z >> 31));
+}
+__device__ __forceinline__ bool nb_keep(const DropCfg& d, uint32_t idx) {
+  const uint32_t h = nb_hash32((idx >> 1) * 0x9E3779B9U + d.key);
+  const uint32_t u = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return u >= d.thr16;
+}
+// decisions for 4 consecutive elements idx..idx+3 (idx % 4 == 0): bit i set = keep
+__device__ __forceinline__ uint32_t nb_keep4(const DropCfg& d, uint32_t idx) {
+  const uint32_t h0 = nb_hash32((idx >> 1) * 0x9E3779B9U + d.key);
+  const uint32_t h1 = nb_hash32(((idx >> 1) + 1) * 0x9E3779B9U + d.key);
+  return ((h0 & 0xFFFFu) >= d.thr16 ? 1u : 0u) | ((h0 >> 16) >= d.thr16 ? 2u : 0u) |
+         ((h1 & 0xFFFFu) >= d.thr16 ? 4u : 0u) | ((h1 >> 16) >= d.thr16 ? 8u : 0u);
+}
+static inline DropCfg make_drop(float p, uint64_t seed, uint32_t stream) {
+  DropCfg d;
+  uint32_t thr = (p <= 0.f) ? 0u : (uint32_t)lrintf(p * 65536.0f);
+  if (thr > 65535u) thr = 65535u;
+  d.thr16 = thr;
+  d.scale = 65536.0f / (float)(65536u - thr);
+  d.key = nb_mix_key(seed, stream);
+  return d;
+}

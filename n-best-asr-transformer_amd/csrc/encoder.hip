@@ -1,0 +1,250 @@
+// The whole encoder stack behind one C-ABI call each way (forward / backward): every kernel of
+// every layer is enqueued on the caller's stream from C++, so a training step costs a handful of
+// Python->C transitions instead of ~400, and the sequence is hipGraph-capturable (no allocation, no
+// synchronisation, no default-stream work inside).
+//
+// Activation stash `act` (written by forward, read by backward), T = dtype:
+//   X[0..L]   [M][H] T      X[0] = embedding output, X[l+1] = output of layer l
+//   emb_stats [M][2] f32
+//   per layer: qkv [M][3H] T | ctx [M][H] T | lse [B*heads*S] f32 | r1 [M][H] T | st1 [M][2] f32 |
+//              x1 [M][H] T | u [M][F] T | hact [M][F] T | r2 [M][H] T | st2 [M][2] f32
+// Scratch `ws` (backward): dR | dRd | dB1 | dctx [M][H] T, dBig [M][F] T, dqkv [M][3H] T,
+//              column-reduction partials, split-K slabs, embedding-backward buffer.
+#include "common.h"
+
+namespace {
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ActLayout {
+  size_t esz, X, emb_stats, layer0, layer_stride;
+  size_t o_qkv, o_ctx, o_lse, o_r1, o_st1, o_x1, o_u, o_hact, o_r2, o_st2;
+  size_t total;
+  int64_t M;
+};
+
+static ActLayout act_layout(const nbest_encoder_desc* d) {
+  ActLayout a;
+  a.esz = d->dtype == NBEST_BF16 ? 2 : 4;
+  a.M = (int64_t)d->B * d->S;
+  const size_t MH = al((size_t)a.M * d->H * a.esz), MF = al((size_t)a.M * d->F * a.esz), M3H = al((size_t)a.M * 3 * d->H * a.esz);
+  const size_t st = al((size_t)a.M * 2 * sizeof(float)), lse = al((size_t)d->B * d->heads * d->S * sizeof(float));
+  size_t o = 0;
+  a.X = o; o += (size_t)(d->L + 1) * MH;
+  a.emb_stats = o; o += st;
+  a.layer0 = o;
+  size_t p = 0;
+  a.o_qkv = p; p += M3H;
+  a.o_ctx = p; p += MH;
+  a.o_lse = p; p += lse;
+  a.o_r1 = p; p += MH;
+  a.o_st1 = p; p += st;
+  a.o_x1 = p; p += MH;
+  a.o_u = p; p += MF;
+  a.o_hact = p; p += MF;
+  a.o_r2 = p; p += MH;
+  a.o_st2 = p; p += st;
+  a.layer_stride = p;
+  a.total = o + (size_t)d->L * p;
+  return a;
+}
+
+struct WsLayout {
+  size_t dR, dRd, dB1, dctx, dBig, dqkv, red, slab, slab_bytes, red_bytes, emb, emb_bytes, total;
+};
+
+static size_t max_splitk_bytes(const nbest_encoder_desc* d, int64_t M) {
+  size_t mx = 0;
+  const int64_t shapes[4][2] = {{3 * (int64_t)d->H, d->H}, {d->H, d->H}, {d->F, d->H}, {d->H, d->F}};
+  for (int i = 0; i < 4; ++i) {
+    nbest_gemm_args g = {};
+    g.M = shapes[i][0]; g.N = shapes[i][1]; g.K = M; g.trans_a = g.trans_b = 1; g.epilogue = NBEST_EPI_F32_SPLITK;
+    g.dtype = d->dtype;
+    const size_t b = nbest_gemm_ws_bytes(&g);
+    if (b > mx) mx = b;
+  }
+  return mx;
+}
+
+static WsLayout ws_layout(const nbest_encoder_desc* d) {
+  WsLayout w;
+  const size_t esz = d->dtype == NBEST_BF16 ? 2 : 4;
+  const int64_t M = (int64_t)d->B * d->S;
+  const size_t MH = al((size_t)M * d->H * esz), MF = al((size_t)M * d->F * esz), M3H = al((size_t)M * 3 * d->H * esz);
+  size_t o = 0;
+  w.dR = o; o += MH;
+  w.dRd = o; o += MH;
+  w.dB1 = o; o += MH;
+  w.dctx = o; o += MH;
+  w.dBig = o; o += MF;
+  w.dqkv = o; o += M3H;
+  const int64_t maxN = d->F > 3 * d->H ? d->F : 3 * d->H;
+  w.red_bytes = al(nbest_rowred_ws_bytes(M, maxN));
+  w.red = o; o += w.red_bytes;
+  w.slab_bytes = al(max_splitk_bytes(d, M));
+  w.slab = o; o += w.slab_bytes;
+  w.emb_bytes = al(nbest_embed_bwd_ws_bytes(M, d->H));
+  w.emb = o; o += w.emb_bytes;
+  w.total = o;
+  return w;
+}
+
+static int check_desc(const nbest_encoder_desc* d) {
+  NB_CHECK(d && d->layers_host, NBEST_ERR_ARG, "encoder: null descriptor");
+  NB_CHECK(d->dtype == NBEST_F32 || d->dtype == NBEST_BF16, NBEST_ERR_DTYPE, "encoder: bad dtype %d", d->dtype);
+  NB_CHECK(d->B > 0 && d->S > 0 && d->L > 0 && d->heads > 0, NBEST_ERR_SHAPE, "encoder: bad shape");
+  NB_CHECK(d->H == d->heads * 64, NBEST_ERR_SHAPE, "encoder: hidden %d != heads %d x 64", d->H, d->heads);
+  if (d->dtype == NBEST_BF16)
+    NB_CHECK(d->H % 128 == 0 && d->F % 128 == 0, NBEST_ERR_SHAPE, "encoder(bf16): H and F must be multiples of 128");
+  return NBEST_OK;
+}
+
+struct Ptrs {
+  const char* wts;   // matrices / tables, dtype
+  const float* prm;  // fp32 master (biases, LayerNorm)
+  size_t esz;
+  const void* W(int64_t off) const { return wts + (size_t)off * esz; }
+  const float* P(int64_t off) const { return prm + off; }
+};
+
+static int gemm(int dtype, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                int64_t ldc, int ta, int tb, int epi, const float* bias, const void* R, int64_t ldr, void* U, int64_t ldu,
+                void* ws, size_t ws_bytes, int accumulate, float drop_p, uint64_t seed, uint32_t stream_id, hipStream_t st) {
+  nbest_gemm_args g = {};
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.R = R; g.U = U; g.ws = ws; g.ws_bytes = ws_bytes;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldu = ldu;
+  g.trans_a = ta; g.trans_b = tb; g.epilogue = epi; g.dtype = dtype; g.accumulate = accumulate;
+  g.drop_p = drop_p; g.drop_stream = stream_id; g.seed = seed;
+  return nbest_gemm(&g, (nbest_stream_t)st);
+}
+
+#define RUN(x)          \
+  do {                  \
+    int rc__ = (x);     \
+    if (rc__) return rc__; \
+  } while (0)
+
+}  // namespace
+
+extern "C" size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d) { return d ? act_layout(d).total : 0; }
+extern "C" size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d) { return d ? ws_layout(d).total : 0; }
+
+extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wts, const float* prm, const int64_t* ids,
+                                     const int64_t* seg, const int64_t* pos, const uint8_t* key_mask, void* act, size_t act_bytes,
+                                     void* ws, size_t ws_bytes, void** hidden_out, nbest_stream_t stream) {
+  RUN(check_desc(d));
+  NB_CHECK(wts && prm && ids && pos && key_mask && act, NBEST_ERR_ARG, "encoder_forward: null pointer");
+  const ActLayout a = act_layout(d);
+  NB_CHECK(act_bytes >= a.total, NBEST_ERR_WORKSPACE, "encoder_forward: activation stash too small (%zu < %zu)", act_bytes, a.total);
+  (void)ws; (void)ws_bytes;
+  hipStream_t st = (hipStream_t)stream;
+  const Ptrs P{(const char*)wts, prm, a.esz};
+  char* A = (char*)act;
+  const int64_t M = a.M;
+  const int H = d->H, F = d->F, dt = d->dtype;
+  const size_t MH = al((size_t)M * H * a.esz);
+  auto X = [&](int l) { return (void*)(A + a.X + (size_t)l * MH); };
+  const uint32_t sb = d->drop_stream_base;
+
+  RUN(nbest_embed_ln_fwd(ids, seg, pos, P.W(d->off_word), P.W(d->off_type), P.W(d->off_pos), P.P(d->off_emb_ln_g),
+                         P.P(d->off_emb_ln_b), X(0), (float*)(A + a.emb_stats), M, H, d->ln_eps, dt, d->hidden_drop, d->seed, sb, st));
+  for (int l = 0; l < d->L; ++l) {
+    const nbest_layer_offsets& o = d->layers_host[l];
+    char* Lb = A + a.layer0 + (size_t)l * a.layer_stride;
+    void* qkv = Lb + a.o_qkv; void* ctx = Lb + a.o_ctx; float* lse = (float*)(Lb + a.o_lse);
+    void* r1 = Lb + a.o_r1; float* st1 = (float*)(Lb + a.o_st1); void* x1 = Lb + a.o_x1;
+    void* u = Lb + a.o_u; void* hact = Lb + a.o_hact; void* r2 = Lb + a.o_r2; float* st2 = (float*)(Lb + a.o_st2);
+    const uint32_t s0 = sb + 1 + 4 * l;
+    // QKV projection: [M,H] x [3H,H]^T + b
+    RUN(gemm(dt, X(l), P.W(o.wqkv), qkv, M, 3 * H, H, H, H, 3 * H, 0, 0, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, 0, nullptr, 0,
+             nullptr, 0, 0, 0.f, 0, 0, st));
+    RUN(nbest_attention_fwd(qkv, key_mask, ctx, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream));
+    // attention output projection + dropout + residual, then LayerNorm
+    RUN(gemm(dt, ctx, P.W(o.wo), r1, M, H, H, H, H, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), H, nullptr, 0, nullptr, 0, 0,
+             d->hidden_drop, d->seed, s0 + 1, st));
+    RUN(nbest_layernorm_fwd(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, st1, M, H, d->ln_eps, dt, stream));
+    // FFN up + bias + GELU (pre-activation kept for the backward)
+    RUN(gemm(dt, x1, P.W(o.w1), hact, M, F, H, H, H, F, 0, 0, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, 0, u, F, nullptr, 0, 0, 0.f,
+             0, 0, st));
+    // FFN down + dropout + residual, then LayerNorm
+    RUN(gemm(dt, hact, P.W(o.w2), r2, M, H, F, F, F, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.b2), x1, H, nullptr, 0, nullptr, 0, 0,
+             d->hidden_drop, d->seed, s0 + 2, st));
+    RUN(nbest_layernorm_fwd(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), st2, M, H, d->ln_eps, dt, stream));
+  }
+  if (hidden_out) *hidden_out = X(d->L);
+  return NBEST_OK;
+}
+
+extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* wts, const float* prm, float* grad,
+                                      const int64_t* ids, const int64_t* seg, const int64_t* pos, const uint8_t* key_mask,
+                                      void* act, size_t act_bytes, void* dhidden, void* ws, size_t ws_bytes, int accumulate,
+                                      nbest_stream_t stream) {
+  RUN(check_desc(d));
+  NB_CHECK(wts && prm && grad && ids && pos && key_mask && act && dhidden && ws, NBEST_ERR_ARG, "encoder_backward: null pointer");
+  const ActLayout a = act_layout(d);
+  const WsLayout w = ws_layout(d);
+  NB_CHECK(act_bytes >= a.total, NBEST_ERR_WORKSPACE, "encoder_backward: activation stash too small");
+  NB_CHECK(ws_bytes >= w.total, NBEST_ERR_WORKSPACE, "encoder_backward: workspace too small (%zu < %zu)", ws_bytes, w.total);
+  hipStream_t st = (hipStream_t)stream;
+  const Ptrs P{(const char*)wts, prm, a.esz};
+  char* A = (char*)act;
+  char* W = (char*)ws;
+  const int64_t M = a.M;
+  const int H = d->H, F = d->F, dt = d->dtype;
+  const size_t MH = al((size_t)M * H * a.esz);
+  auto X = [&](int l) { return (void*)(A + a.X + (size_t)l * MH); };
+  auto G = [&](int64_t off) { return grad + off; };
+  void* dA = dhidden;
+  void* dR = W + w.dR;
+  const bool hdrop = d->hidden_drop > 0.f;
+  void* dRd = hdrop ? (void*)(W + w.dRd) : dR;
+  void* dB1 = W + w.dB1; void* dctx = W + w.dctx; void* dBig = W + w.dBig; void* dqkv = W + w.dqkv;
+  void* red = W + w.red; void* slab = W + w.slab;
+  const uint32_t sb = d->drop_stream_base;
+
+  for (int l = d->L - 1; l >= 0; --l) {
+    const nbest_layer_offsets& o = d->layers_host[l];
+    char* Lb = A + a.layer0 + (size_t)l * a.layer_stride;
+    void* qkv = Lb + a.o_qkv; void* ctx = Lb + a.o_ctx; float* lse = (float*)(Lb + a.o_lse);
+    void* r1 = Lb + a.o_r1; float* st1 = (float*)(Lb + a.o_st1); void* x1 = Lb + a.o_x1;
+    void* u = Lb + a.o_u; void* hact = Lb + a.o_hact; void* r2 = Lb + a.o_r2; float* st2 = (float*)(Lb + a.o_st2);
+    const uint32_t s0 = sb + 1 + 4 * l;
+    // LN2 backward: dR (residual branch), dRd (dense branch, under the dropout mask), db2
+    RUN(nbest_layernorm_bwd(dA, r2, st2, P.P(o.ln2_g), dR, hdrop ? dRd : nullptr, G(o.ln2_g), G(o.ln2_b), G(o.b2), M, H, dt, accumulate,
+                            d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream));
+    // FFN-down: dgrad fused with GELU' -> dU ; wgrad
+    RUN(gemm(dt, dRd, P.W(o.w2), dBig, M, F, H, H, F, F, 0, 1, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, nullptr, 0, 0, 0.f, 0, 0, st));
+    RUN(gemm(dt, dRd, hact, G(o.w2), H, F, M, H, F, F, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
+             accumulate, 0.f, 0, 0, st));
+    RUN(nbest_colsum(dBig, G(o.b1), M, F, F, dt, accumulate, red, w.red_bytes, stream));
+    // FFN-up: dgrad + residual gradient ; wgrad
+    RUN(gemm(dt, dBig, P.W(o.w1), dB1, M, H, F, F, H, H, 0, 1, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
+             accumulate, 0.f, 0, 0, st));
+    // LN1 backward
+    RUN(nbest_layernorm_bwd(dB1, r1, st1, P.P(o.ln1_g), dR, hdrop ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt, accumulate,
+                            d->hidden_drop, d->seed, s0 + 1, red, w.red_bytes, stream));
+    // attention output projection: dgrad ; wgrad
+    RUN(gemm(dt, dRd, P.W(o.wo), dctx, M, H, H, H, H, H, 0, 1, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
+             accumulate, 0.f, 0, 0, st));
+    // attention backward -> dqkv ; QKV bias gradient
+    RUN(nbest_attention_bwd(qkv, key_mask, ctx, dctx, lse, dqkv, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream));
+    RUN(nbest_colsum(dqkv, G(o.bqkv), M, 3 * H, 3 * H, dt, accumulate, red, w.red_bytes, stream));
+    // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
+    RUN(gemm(dt, dqkv, P.W(o.wqkv), dA, M, H, 3 * H, 3 * H, H, H, 0, 1, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
+             w.slab_bytes, accumulate, 0.f, 0, 0, st));
+  }
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(G(d->off_word), 0, (size_t)d->vocab * H * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(G(d->off_pos), 0, (size_t)d->max_pos * H * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(G(d->off_type), 0, (size_t)d->n_types * H * sizeof(float), st);
+    NB_CHECK(e == hipSuccess, NBEST_ERR_LAUNCH, "encoder_backward: memset failed: %s", hipGetErrorString(e));
+  }
+  RUN(nbest_embed_ln_bwd(ids, seg, pos, P.W(d->off_word), P.W(d->off_type), P.W(d->off_pos), P.P(d->off_emb_ln_g),
+                         (const float*)(A + a.emb_stats), dA, G(d->off_word), G(d->off_type), G(d->off_pos), G(d->off_emb_ln_g),
+                         G(d->off_emb_ln_b), d->B, d->S, H, d->n_types, dt, d->word_pad_id, d->pos_pad_id, accumulate,
+                         d->hidden_drop, d->seed, sb, W + w.emb, w.emb_bytes, stream));
+  return NBEST_OK;
+}

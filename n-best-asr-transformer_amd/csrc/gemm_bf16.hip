@@ -1,0 +1,289 @@
+// K2/K4/K6: bf16 GEMM on MFMA (v_mfma_f32_16x16x32_bf16) for gfx950, fp32 accumulate, fused epilogues.
+//
+//   C[M,N] = epi( op(A)[M,K] . op(B)[K,N] )       block tile 128 x 128 x 64, 4 waves (2 x 2), wave tile 64 x 64
+//
+// HBM -> LDS : buffer_load_dwordx4 ... lds (LDS-DMA, 16 B/lane, no VGPR round trip).  The buffer
+//              descriptor's range check returns ZERO for rows past the end of a matrix, which is how
+//              ragged token counts (M, or K of a weight gradient) are handled without branches.
+// LDS image  : LDS-DMA writes lane-linear, so the bank-conflict swizzle is applied to the per-lane
+//              SOURCE address and to the read address (same involution on both sides):
+//                k-contiguous operand  [128 rows][64 k]  128-B rows : chunk16 ^= (row>>1)&7   -> ds_read_b128
+//                k-strided operand     [64 k][128 cols]  256-B rows : chunk16 ^= 2*(k&3)+8*((k>>3)&1) -> ds_read_b64_tr_b16
+//              (transposed read = the hardware 4x16 transpose, so A^T / B^T operands of the backward
+//              GEMMs need no transposed copy of activations or weights in HBM).
+// pipeline   : 2 LDS stages; the DMA of tile t+1 is in flight while tile t is multiplied; one barrier per tile.
+// MFMA       : operands are passed SWAPPED (B fragment first) so each lane ends up with 4 CONSECUTIVE
+//              output columns of one row -> 8-byte bf16 / 16-byte fp32 epilogue accesses, bias as one float4.
+// grid       : 1-D, XCD-aware bijective remap so the n-tiles that share an A row panel run on one XCD (one L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kTileBytes = BM * BK * 2;       // 16 KiB per operand tile
+constexpr int kStageBytes = 2 * kTileBytes;   // A + B
+constexpr int kLdsBytes = 2 * kStageBytes;    // 2 stages = 64 KiB
+
+struct GemmP {
+  const bf16* A; const bf16* B; void* C; const float* bias; const bf16* R; bf16* U; float* slab;
+  int64_t M, N, K, lda, ldb, ldc, ldr, ldu;
+  int64_t k_per_split;
+  int tiles_m, tiles_n, splits, accumulate;
+  uint32_t a_bytes, b_bytes;
+  DropCfg drop;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---- staging: one operand tile, 4 LDS-DMA instructions per thread -------------------------------
+template <bool TR>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, char* lds_tile, int64_t row0, int64_t k0, int64_t ld,
+                                           int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = i * 256 + tid;  // linear 16-B chunk index inside the tile
+    uint32_t voff;
+    if (!TR) {
+      const int row = p >> 3, slot = p & 7;
+      const int kc = slot ^ ((row >> 1) & 7);
+      voff = (uint32_t)(((row0 + row) * ld + k0 + kc * 8) * 2);
+    } else {
+      const int krow = p >> 4, slot = p & 15;
+      const int mc = slot ^ (2 * (krow & 3) + 8 * ((krow >> 3) & 1));
+      voff = (uint32_t)(((k0 + krow) * ld + row0 + mc * 8) * 2);
+    }
+    char* dst = lds_tile + (i * 256 + wave * 64) * 16;  // wave-uniform; the DMA adds lane*16
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, 0, 0, 0);
+  }
+}
+
+// ---- fragment reads ------------------------------------------------------------------------------
+// 16 rows x 32 k fragment for v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8*(l>>4) + j
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row_base, int ks, int lane) {
+  if (!TR) {
+    const int row = row_base + (lane & 15);
+    const int kc = (lane >> 4) + 4 * ks;
+    return *(const bf16x8*)(lds_tile + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+    const int col = row_base + 4 * pq;
+    bf16x8 out;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int krow = 32 * ks + 8 * g + 4 * half + q;
+      const int f = 2 * (krow & 3) + 8 * ((krow >> 3) & 1);
+      const char* addr = lds_tile + krow * 256 + (((col >> 3) ^ f) << 4) + ((col & 4) ? 8 : 0);
+      bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)addr);
+      out[4 * half + 0] = v[0]; out[4 * half + 1] = v[1]; out[4 * half + 2] = v[2]; out[4 * half + 3] = v[3];
+    }
+    return out;
+  }
+}
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = id / tiles, t = id - z * tiles;
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+  const int64_t kbeg = (int64_t)z * p.k_per_split;
+  const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  if (nk > 0) {
+    stage_tile<TA>(rsA, lds, m0, kbeg, p.lda, tid);
+    stage_tile<TB>(rsB, lds + kTileBytes, n0, kbeg, p.ldb, tid);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt landed for every wave; every wave is done reading the other stage
+    const char* cur = lds + (kt & 1) * kStageBytes;
+    if (kt + 1 < nk) {
+      char* nxt = lds + ((kt + 1) & 1) * kStageBytes;
+      const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
+      stage_tile<TA>(rsA, nxt, m0, k0, p.lda, tid);
+      stage_tile<TB>(rsB, nxt + kTileBytes, n0, k0, p.ldb, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(cur + kTileBytes, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds C[m][n4 .. n4+3] ------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n4 = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      f32x4 v = acc[i][j];
+      if (EPI == NBEST_EPI_F32_SPLITK) {
+        if (p.splits > 1) {
+          *(f32x4*)(p.slab + ((int64_t)z * p.M + m) * p.N + n4) = v;
+        } else {
+          float* c = (float*)p.C + m * p.ldc + n4;
+          if (p.accumulate) v += *(const f32x4*)c;
+          *(f32x4*)c = v;
+        }
+        continue;
+      }
+      if (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES)
+        v += *(const f32x4*)(p.bias + n4);
+      if (EPI == NBEST_EPI_BIAS_GELU) {
+        Vec4<bf16>::store(p.U + m * p.ldu + n4, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+      }
+      if (EPI == NBEST_EPI_BIAS_DROP_RES) {
+        if (p.drop.thr16) {
+          const uint32_t k = nb_keep4(p.drop, (uint32_t)(m * p.N + n4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
+        }
+        v += Vec4<bf16>::load(p.R + m * p.ldr + n4);
+      }
+      if (EPI == NBEST_EPI_RES) v += Vec4<bf16>::load(p.R + m * p.ldr + n4);
+      if (EPI == NBEST_EPI_DGELU) {
+        const f32x4 u = Vec4<bf16>::load(p.U + m * p.ldu + n4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(u[e]);
+      }
+      Vec4<bf16>::store((bf16*)p.C + m * p.ldc + n4, v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, int64_t MN,
+                                                            int64_t N, int64_t ldc, int splits, int accumulate) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    f32x4 s = *(const f32x4*)(slab + i);
+    for (int z = 1; z < splits; ++z) s += *(const f32x4*)(slab + (int64_t)z * MN + i);
+    const int64_t m = i / N, n = i - m * N;
+    float* c = C + m * ldc + n;
+    if (accumulate) s += *(const f32x4*)c;
+    *(f32x4*)c = s;
+  }
+}
+
+static int choose_splits(const nbest_gemm_args* a, int64_t* kps) {
+  const int64_t tiles = ((a->M + BM - 1) / BM) * (a->N / BN);
+  int64_t splits = 1;
+  if (a->epilogue == NBEST_EPI_F32_SPLITK) {
+    splits = (768 + tiles - 1) / tiles;
+    const int64_t maxs = (a->K + 255) / 256;
+    if (splits > maxs) splits = maxs;
+    if (splits > 32) splits = 32;
+    if (splits < 1) splits = 1;
+  }
+  int64_t k = (a->K + splits - 1) / splits;
+  k = (k + BK - 1) / BK * BK;
+  splits = (a->K + k - 1) / k;
+  *kps = k;
+  return (int)splits;
+}
+
+template <bool TA, bool TB>
+static int launch_epi(const GemmP& p, int epi, int grid, hipStream_t st) {
+#define L(E)                                                                          \
+  case E:                                                                             \
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes); \
+    gemm_bf16_kernel<TA, TB, E><<<grid, 256, kLdsBytes, st>>>(p);                      \
+    break;
+  switch (epi) {
+    L(NBEST_EPI_NONE) L(NBEST_EPI_BIAS) L(NBEST_EPI_BIAS_GELU) L(NBEST_EPI_BIAS_DROP_RES) L(NBEST_EPI_DGELU)
+    L(NBEST_EPI_RES) L(NBEST_EPI_F32_SPLITK)
+    default:
+      nbest_set_error("gemm: bad epilogue %d", epi);
+      return NBEST_ERR_ARG;
+  }
+#undef L
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+}  // namespace
+
+size_t nbest_gemm_bf16_ws_bytes(const nbest_gemm_args* a) {
+  if (a->epilogue != NBEST_EPI_F32_SPLITK) return 0;
+  int64_t kps;
+  const int splits = choose_splits(a, &kps);
+  return splits > 1 ? (size_t)splits * a->M * a->N * sizeof(float) : 0;
+}
+
+int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st) {
+  NB_CHECK(a->N % BN == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld must be a multiple of %d", (long long)a->N, BN);
+  NB_CHECK(a->trans_a || a->K % BK == 0, NBEST_ERR_SHAPE, "gemm(bf16): K=%lld must be a multiple of %d", (long long)a->K, BK);
+  NB_CHECK(!(a->trans_a && !a->trans_b), NBEST_ERR_ARG, "gemm(bf16): trans_a without trans_b is not built");
+  NB_CHECK(!a->trans_a || a->M % BM == 0, NBEST_ERR_SHAPE, "gemm(bf16): trans_a needs M %% 128 == 0");
+  NB_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0, NBEST_ERR_ALIGN, "gemm(bf16): leading dimensions must be multiples of 8");
+  NB_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0, NBEST_ERR_ALIGN,
+           "gemm(bf16): pointers must be 16-byte aligned");
+  GemmP p;
+  p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C; p.bias = a->bias; p.R = (const bf16*)a->R; p.U = (bf16*)a->U;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldu = a->ldu;
+  p.tiles_m = (int)((a->M + BM - 1) / BM);
+  p.tiles_n = (int)(a->N / BN);
+  p.splits = choose_splits(a, &p.k_per_split);
+  p.accumulate = a->accumulate;
+  p.slab = (float*)a->ws;
+  const int64_t a_rows = a->trans_a ? a->K : a->M, a_cols = a->trans_a ? a->M : a->K;
+  const int64_t b_rows = a->trans_b ? a->K : a->N, b_cols = a->trans_b ? a->N : a->K;
+  const int64_t ab = ((a_rows - 1) * a->lda + a_cols) * 2, bb = ((b_rows - 1) * a->ldb + b_cols) * 2;
+  NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm(bf16): operand larger than 4 GiB");
+  p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
+  NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm(bf16): dropout counter overflow");
+  const int epi = a->epilogue;
+  if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)
+    NB_CHECK(a->bias, NBEST_ERR_ARG, "gemm: epilogue %d needs bias", epi);
+  if (epi == NBEST_EPI_BIAS_DROP_RES || epi == NBEST_EPI_RES) NB_CHECK(a->R && a->ldr % 4 == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs R", epi);
+  if (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU) NB_CHECK(a->U && a->ldu % 4 == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs U", epi);
+  if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1)
+    NB_CHECK(a->ws && a->ws_bytes >= (size_t)p.splits * a->M * a->N * sizeof(float), NBEST_ERR_WORKSPACE,
+             "gemm: split-K workspace too small (%zu < %zu)", a->ws_bytes, (size_t)p.splits * a->M * a->N * sizeof(float));
+  const int grid = p.tiles_m * p.tiles_n * p.splits;
+  int rc;
+  if (!a->trans_a && !a->trans_b) rc = launch_epi<false, false>(p, epi, grid, st);
+  else if (!a->trans_a && a->trans_b) rc = launch_epi<false, true>(p, epi, grid, st);
+  else rc = launch_epi<true, true>(p, epi, grid, st);
+  if (rc) return rc;
+  if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1) {
+    const int64_t MN = a->M * a->N;
+    int64_t g = (MN / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    splitk_reduce_kernel<<<(int)g, 256, 0, st>>>(p.slab, (float*)a->C, MN, a->N, a->ldc, p.splits, a->accumulate);
+    NB_LAUNCH_CHECK();
+  }
+  return NBEST_OK;
+}

@@ -1,0 +1,138 @@
+// fp32 GEMM for the NBEST_F32 parity path: plain fmaf accumulation on the vector ALUs (exact fp32,
+// k-ordered), 64x64x16 LDS tiles, any M/N/K, all four storage combinations, same epilogues as the
+// bf16 MFMA kernel.  It exists so the hand-written backward formulas and the host orchestration can
+// be checked against the oracle at 1e-4 without bf16 rounding in the way; it is not a fast path.
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16;
+
+struct GemmF {
+  const float* A; const float* B; float* C; const float* bias; const float* R; float* U;
+  int64_t M, N, K, lda, ldb, ldc, ldr, ldu;
+  int accumulate;
+  DropCfg drop;
+};
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
+  __shared__ float As[TK][TM + 4];
+  __shared__ float Bs[TK][TN + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
+  float acc[4][4] = {};
+  for (int64_t k0 = 0; k0 < p.K; k0 += TK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      int mm, kk;
+      if (TA) { kk = idx >> 6; mm = idx & 63; } else { mm = idx >> 4; kk = idx & 15; }
+      const int64_t m = m0 + mm, k = k0 + kk;
+      float v = 0.f;
+      if (m < p.M && k < p.K) v = TA ? p.A[k * p.lda + m] : p.A[m * p.lda + k];
+      As[kk][mm] = v;
+      int nn;
+      if (TB) { kk = idx >> 6; nn = idx & 63; } else { nn = idx >> 4; kk = idx & 15; }
+      const int64_t n = n0 + nn;
+      const int64_t kb = k0 + kk;
+      v = 0.f;
+      if (n < p.N && kb < p.K) v = TB ? p.B[kb * p.ldb + n] : p.B[n * p.ldb + kb];
+      Bs[kk][nn] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + ty * 4 + i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + tx * 4 + j;
+      if (n >= p.N) continue;
+      float v = acc[i][j];
+      if (EPI == NBEST_EPI_F32_SPLITK) {
+        float* c = p.C + m * p.ldc + n;
+        *c = p.accumulate ? *c + v : v;
+        continue;
+      }
+      if (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES) v += p.bias[n];
+      if (EPI == NBEST_EPI_BIAS_GELU) { p.U[m * p.ldu + n] = v; v = gelu_f(v); }
+      if (EPI == NBEST_EPI_BIAS_DROP_RES) {
+        if (p.drop.thr16) v = nb_keep(p.drop, (uint32_t)(m * p.N + n)) ? v * p.drop.scale : 0.f;
+        v += p.R[m * p.ldr + n];
+      }
+      if (EPI == NBEST_EPI_RES) v += p.R[m * p.ldr + n];
+      if (EPI == NBEST_EPI_DGELU) v *= dgelu_f(p.U[m * p.ldu + n]);
+      p.C[m * p.ldc + n] = v;
+    }
+  }
+}
+
+template <bool TA, bool TB>
+static int launch_epi(const GemmF& p, int epi, dim3 grid, hipStream_t st) {
+#define L(E) case E: gemm_f32_kernel<TA, TB, E><<<grid, 256, 0, st>>>(p); break;
+  switch (epi) {
+    L(NBEST_EPI_NONE) L(NBEST_EPI_BIAS) L(NBEST_EPI_BIAS_GELU) L(NBEST_EPI_BIAS_DROP_RES) L(NBEST_EPI_DGELU)
+    L(NBEST_EPI_RES) L(NBEST_EPI_F32_SPLITK)
+    default:
+      nbest_set_error("gemm: bad epilogue %d", epi);
+      return NBEST_ERR_ARG;
+  }
+#undef L
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+}  // namespace
+
+int nbest_gemm_f32(const nbest_gemm_args* a, hipStream_t st) {
+  GemmF p;
+  p.A = (const float*)a->A; p.B = (const float*)a->B; p.C = (float*)a->C; p.bias = a->bias; p.R = (const float*)a->R;
+  p.U = (float*)a->U;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldu = a->ldu;
+  p.accumulate = a->accumulate;
+  p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
+  const int epi = a->epilogue;
+  if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)
+    NB_CHECK(a->bias, NBEST_ERR_ARG, "gemm: epilogue %d needs bias", epi);
+  if (epi == NBEST_EPI_BIAS_DROP_RES || epi == NBEST_EPI_RES) NB_CHECK(a->R, NBEST_ERR_ARG, "gemm: epilogue %d needs R", epi);
+  if (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU) NB_CHECK(a->U, NBEST_ERR_ARG, "gemm: epilogue %d needs U", epi);
+  dim3 grid((unsigned)((a->N + TN - 1) / TN), (unsigned)((a->M + TM - 1) / TM));
+  if (!a->trans_a && !a->trans_b) return launch_epi<false, false>(p, epi, grid, st);
+  if (!a->trans_a && a->trans_b) return launch_epi<false, true>(p, epi, grid, st);
+  if (a->trans_a && a->trans_b) return launch_epi<true, true>(p, epi, grid, st);
+  return launch_epi<true, false>(p, epi, grid, st);
+}
+
+// ---- public dispatcher ----------------------------------------------------------------------------
+size_t nbest_gemm_bf16_ws_bytes(const nbest_gemm_args* a);
+int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st);
+
+extern "C" size_t nbest_gemm_ws_bytes(const nbest_gemm_args* a) {
+  if (!a || a->dtype != NBEST_BF16) return 0;
+  return nbest_gemm_bf16_ws_bytes(a);
+}
+
+extern "C" int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream) {
+  NB_CHECK(a && a->A && a->B && a->C, NBEST_ERR_ARG, "gemm: null pointer");
+  NB_CHECK(a->M > 0 && a->N > 0 && a->K > 0, NBEST_ERR_SHAPE, "gemm: bad shape %lld x %lld x %lld", (long long)a->M,
+           (long long)a->N, (long long)a->K);
+  if (a->dtype == NBEST_F32) return nbest_gemm_f32(a, (hipStream_t)stream);
+  if (a->dtype == NBEST_BF16) return nbest_gemm_bf16(a, (hipStream_t)stream);
+  nbest_set_error("gemm: bad dtype %d", a->dtype);
+  return NBEST_ERR_DTYPE;
+}

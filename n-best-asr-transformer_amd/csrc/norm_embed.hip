@@ -1,0 +1,559 @@
+// HBM-bound row kernels: LayerNorm fwd/bwd (K5), embedding gather+LN fwd/bwd (K1/K1b), column sums
+// (bias gradients), CLS-gradient scatter, fp32->bf16 arena cast.
+//
+// Layout: activations [M][H] row-major.  One wave64 owns one row at a time and keeps it in
+// registers (H/4 float4 chunks, chunk c on lane c%64) - a row is read from HBM exactly once per
+// pass; statistics are wave-shuffle reductions in fp32.  Loads are 16 B (fp32) / 8 B (bf16) per lane.
+// Column reductions (dgamma, dbeta, bias gradients) are deterministic: per-block partial rows in a
+// workspace + a finalize kernel (no float atomics on the gradient of a parameter).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxRowredBlocks = 1024;
+static inline int rowred_blocks(int64_t M) {
+  int64_t b = (M + 15) / 16;
+  if (b < 1) b = 1;
+  if (b > kMaxRowredBlocks) b = kMaxRowredBlocks;
+  return (int)b;
+}
+
+__device__ __forceinline__ float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ stats, int64_t M, int H, float eps) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, nvec = H >> 2;
+  const float invH = 1.0f / (float)H;
+  for (int64_t row = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * wpb) {
+    const T* xr = x + row * H;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) { v[i] = Vec4<T>::load(xr + 4 * c); s += sum4(v[i]); } else v[i] = f32x4{0, 0, 0, 0};
+    }
+    const float mean = wave_sum(s) * invH;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) { f32x4 d = v[i] - mean; q += sum4(d * d); }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * invH + eps);
+    T* yr = y + row * H;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4 g = *(const f32x4*)(gamma + 4 * c), b = *(const f32x4*)(beta + 4 * c);
+        Vec4<T>::store(yr + 4 * c, (v[i] - mean) * rstd * g + b);
+      }
+    }
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+}
+
+// partials layout: part[k][blk][H], k = 0 dgamma, 1 dbeta, 2 dbias(sum of dx)
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     T* __restrict__ dx, T* __restrict__ dx_drop, float* __restrict__ part,
+                                                     int64_t M, int H, int rows_per_block, int with_dbias, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [3][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, nvec = H >> 2;
+  const float invH = 1.0f / (float)H;
+  for (int i = threadIdx.x; i < 3 * H; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  f32x4 ag[VPL], ab[VPL], ad[VPL], gm[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    ag[i] = ab[i] = ad[i] = f32x4{0, 0, 0, 0};
+    const int c = lane + 64 * i;
+    gm[i] = (c < nvec) ? *(const f32x4*)(gamma + 4 * c) : f32x4{0, 0, 0, 0};
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  for (int64_t row = r0 + wave; row < r1; row += wpb) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    f32x4 xh[VPL], g[VPL], d[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        xh[i] = (Vec4<T>::load(x + row * H + 4 * c) - mean) * rstd;
+        d[i] = Vec4<T>::load(dy + row * H + 4 * c);
+        g[i] = d[i] * gm[i];
+        s1 += sum4(g[i]);
+        s2 += sum4(g[i] * xh[i]);
+      } else {
+        xh[i] = g[i] = d[i] = f32x4{0, 0, 0, 0};
+      }
+    }
+    s1 = wave_sum(s1) * invH;
+    s2 = wave_sum(s2) * invH;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4 o = (g[i] - s1 - xh[i] * s2) * rstd;
+        Vec4<T>::store(dx + row * H + 4 * c, o);
+        ag[i] += d[i] * xh[i];
+        ab[i] += d[i];
+        if (drop.thr16) {  // gradient that flows into the dense layer under the (regenerated) dropout mask
+          const uint32_t k = nb_keep4(drop, (uint32_t)(row * H + 4 * c));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (k >> e & 1) ? o[e] * drop.scale : 0.f;
+          Vec4<T>::store(dx_drop + row * H + 4 * c, o);
+        }
+        ad[i] += o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(&acc[4 * c + e], ag[i][e]);
+        atomicAdd(&acc[H + 4 * c + e], ab[i][e]);
+        if (with_dbias) atomicAdd(&acc[2 * H + 4 * c + e], ad[i][e]);
+      }
+    }
+  }
+  __syncthreads();
+  const int nblk = gridDim.x;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    part[((int64_t)0 * nblk + blockIdx.x) * H + i] = acc[i];
+    part[((int64_t)1 * nblk + blockIdx.x) * H + i] = acc[H + i];
+    if (with_dbias) part[((int64_t)2 * nblk + blockIdx.x) * H + i] = acc[2 * H + i];
+  }
+}
+
+// out_k[col] (+)= sum_blk part[k][blk][col];  grid (ceil(N/64), nout), block (64,4)
+struct RowredOut {
+  float* out[3];
+  int accumulate[3];
+};
+__global__ void rowred_finalize_kernel(const float* __restrict__ part, int nblk, int N, RowredOut o) {
+  __shared__ float sm[4][64];
+  const int k = blockIdx.y;
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  float s = 0.f;
+  if (col < N && o.out[k] != nullptr)
+    for (int b = threadIdx.y; b < nblk; b += 4) s += part[((int64_t)k * nblk + b) * N + col];
+  sm[threadIdx.y][threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y == 0 && col < N && o.out[k] != nullptr) {
+    s = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    o.out[k][col] = o.accumulate[k] ? o.out[k][col] + s : s;
+  }
+}
+
+// column sums of X[M][N] (ld): block = 64 column-float4 lanes x 4 row lanes; grid (ceil(N/256), nblk)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ part, int64_t M,
+                                                     int64_t N, int64_t ld, int rows_per_block) {
+  __shared__ f32x4 sm[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 256 + 4 * tx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  f32x4 a = {0, 0, 0, 0};
+  if (col < N)
+    for (int64_t r = r0 + ty; r < r1; r += 4) a += Vec4<T>::load(X + r * ld + col);
+  sm[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && col < N) {
+    a = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
+    *(f32x4*)(part + (int64_t)blockIdx.y * N + col) = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
+                                                        const int64_t* __restrict__ pos, const T* __restrict__ word,
+                                                        const T* __restrict__ type, const T* __restrict__ ptab,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        T* __restrict__ out, float* __restrict__ stats, int64_t M, int H,
+                                                        float eps, DropCfg drop) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, nvec = H >> 2;
+  const float invH = 1.0f / (float)H;
+  for (int64_t row = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * wpb) {
+    const T* wr = word + ids[row] * H;
+    const T* tr = type + (seg ? seg[row] : 0) * H;
+    const T* pr = ptab + pos[row] * H;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        v[i] = (Vec4<T>::load(wr + 4 * c) + Vec4<T>::load(tr + 4 * c)) + Vec4<T>::load(pr + 4 * c);
+        s += sum4(v[i]);
+      } else v[i] = f32x4{0, 0, 0, 0};
+    }
+    const float mean = wave_sum(s) * invH;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) { f32x4 d = v[i] - mean; q += sum4(d * d); }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * invH + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4 g = *(const f32x4*)(gamma + 4 * c), b = *(const f32x4*)(beta + 4 * c);
+        f32x4 o = (v[i] - mean) * rstd * g + b;
+        if (drop.thr16) {
+          const uint32_t k = nb_keep4(drop, (uint32_t)(row * H + 4 * c));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (k >> e & 1) ? o[e] * drop.scale : 0.f;
+        }
+        Vec4<T>::store(out + row * H + 4 * c, o);
+      }
+    }
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  }
+}
+
+// backward A: LN backward per row, de -> de_buf (fp32) and atomically into dword; dgamma/dbeta partials
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
+                                                        const int64_t* __restrict__ pos, const T* __restrict__ word,
+                                                        const T* __restrict__ type, const T* __restrict__ ptab,
+                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                        const T* __restrict__ dout, float* __restrict__ dword,
+                                                        float* __restrict__ de_buf, float* __restrict__ part, int64_t M,
+                                                        int H, int rows_per_block, int64_t word_pad_id, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [2][H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, nvec = H >> 2;
+  const float invH = 1.0f / (float)H;
+  for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  f32x4 ag[VPL], ab[VPL], gm[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    ag[i] = ab[i] = f32x4{0, 0, 0, 0};
+    const int c = lane + 64 * i;
+    gm[i] = (c < nvec) ? *(const f32x4*)(gamma + 4 * c) : f32x4{0, 0, 0, 0};
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  for (int64_t row = r0 + wave; row < r1; row += wpb) {
+    const int64_t id = ids[row];
+    const T* wr = word + id * H;
+    const T* tr = type + (seg ? seg[row] : 0) * H;
+    const T* pr = ptab + pos[row] * H;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    f32x4 xh[VPL], g[VPL], d[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4 e = (Vec4<T>::load(wr + 4 * c) + Vec4<T>::load(tr + 4 * c)) + Vec4<T>::load(pr + 4 * c);
+        xh[i] = (e - mean) * rstd;
+        d[i] = Vec4<T>::load(dout + row * H + 4 * c);
+        if (drop.thr16) {
+          const uint32_t k = nb_keep4(drop, (uint32_t)(row * H + 4 * c));
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) d[i][e2] = (k >> e2 & 1) ? d[i][e2] * drop.scale : 0.f;
+        }
+        g[i] = d[i] * gm[i];
+        s1 += sum4(g[i]);
+        s2 += sum4(g[i] * xh[i]);
+      } else {
+        xh[i] = g[i] = d[i] = f32x4{0, 0, 0, 0};
+      }
+    }
+    s1 = wave_sum(s1) * invH;
+    s2 = wave_sum(s2) * invH;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4 o = (g[i] - s1 - xh[i] * s2) * rstd;
+        *(f32x4*)(de_buf + row * H + 4 * c) = o;
+        if (id != word_pad_id) {
+          float* dw = dword + id * H + 4 * c;
+          atomicAdd(dw + 0, o[0]); atomicAdd(dw + 1, o[1]); atomicAdd(dw + 2, o[2]); atomicAdd(dw + 3, o[3]);
+        }
+        ag[i] += d[i] * xh[i];
+        ab[i] += d[i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(&acc[4 * c + e], ag[i][e]);
+        atomicAdd(&acc[H + 4 * c + e], ab[i][e]);
+      }
+    }
+  }
+  __syncthreads();
+  const int nblk = gridDim.x;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    part[((int64_t)0 * nblk + blockIdx.x) * H + i] = acc[i];
+    part[((int64_t)1 * nblk + blockIdx.x) * H + i] = acc[H + i];
+  }
+}
+
+// backward B: position / token-type table gradients.  Block j owns sequence position j and sums de
+// over the batch in registers for the common key (pos[0*S+j]); rows with another key fall back to
+// atomics.  Token types 0/1 are summed in registers too.  Results are atomically ADDED to the tables.
+__global__ __launch_bounds__(256) void embed_bwd_tables_kernel(const int64_t* __restrict__ seg, const int64_t* __restrict__ pos,
+                                                               const float* __restrict__ de_buf, float* __restrict__ dtype_tab,
+                                                               float* __restrict__ dptab, int B, int S, int H, int n_types,
+                                                               int64_t pos_pad_id) {
+  const int j = blockIdx.x;
+  const int nvec = H >> 2;
+  for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
+    f32x4 ap = {0, 0, 0, 0}, t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+    const int64_t key0 = pos[j];
+    for (int b = 0; b < B; ++b) {
+      const int64_t m = (int64_t)b * S + j;
+      const f32x4 de = *(const f32x4*)(de_buf + m * H + 4 * c);
+      const int64_t key = pos[m];
+      if (key == key0) ap += de;
+      else if (key != pos_pad_id) {
+        float* p = dptab + key * H + 4 * c;
+        atomicAdd(p, de[0]); atomicAdd(p + 1, de[1]); atomicAdd(p + 2, de[2]); atomicAdd(p + 3, de[3]);
+      }
+      const int64_t sv = seg ? seg[m] : 0;
+      if (sv == 0) t0 += de;
+      else if (sv == 1) t1 += de;
+      else {
+        float* p = dtype_tab + sv * H + 4 * c;
+        atomicAdd(p, de[0]); atomicAdd(p + 1, de[1]); atomicAdd(p + 2, de[2]); atomicAdd(p + 3, de[3]);
+      }
+    }
+    if (key0 != pos_pad_id) {
+      float* p = dptab + key0 * H + 4 * c;
+      atomicAdd(p, ap[0]); atomicAdd(p + 1, ap[1]); atomicAdd(p + 2, ap[2]); atomicAdd(p + 3, ap[3]);
+    }
+    {
+      float* p = dtype_tab + 4 * c;
+      atomicAdd(p, t0[0]); atomicAdd(p + 1, t0[1]); atomicAdd(p + 2, t0[2]); atomicAdd(p + 3, t0[3]);
+    }
+    if (n_types > 1) {
+      float* p = dtype_tab + H + 4 * c;
+      atomicAdd(p, t1[0]); atomicAdd(p + 1, t1[1]); atomicAdd(p + 2, t1[2]); atomicAdd(p + 3, t1[3]);
+    }
+  }
+}
+
+template <typename T>
+__global__ void cls_scatter_kernel(const float* __restrict__ dcls, T* __restrict__ dh, int64_t nvec_total, int S, int H) {
+  const int nvec = H >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec_total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nvec;
+    const int c = (int)(i - row * nvec);
+    f32x4 v = {0, 0, 0, 0};
+    if (row % S == 0) v = *(const f32x4*)(dcls + (row / S) * H + 4 * c);
+    Vec4<T>::store(dh + row * H + 4 * c, v);
+  }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    Vec8<float>::load(src + 8 * i, v);
+    Vec8<bf16>::store(dst + 8 * i, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n8 << 3; i < n; ++i) dst[i] = (bf16)src[i];
+}
+
+static inline int vpl_for(int H) { return ((H >> 2) + 63) / 64; }
+static inline int grid_rows(int64_t M, int wpb) {
+  int64_t g = (M + wpb - 1) / wpb;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define DISPATCH_VPL(H, CALL)                                     \
+  do {                                                            \
+    const int vpl__ = vpl_for(H);                                 \
+    if (vpl__ <= 1) { constexpr int VPL = 1; CALL; }              \
+    else if (vpl__ <= 2) { constexpr int VPL = 2; CALL; }         \
+    else if (vpl__ <= 3) { constexpr int VPL = 3; CALL; }         \
+    else if (vpl__ <= 4) { constexpr int VPL = 4; CALL; }         \
+    else { constexpr int VPL = 8; CALL; }                         \
+  } while (0)
+
+static int check_h(int H) {
+  NB_CHECK(H > 0 && H % 4 == 0 && H <= 2048, NBEST_ERR_SHAPE, "hidden size %d must be a multiple of 4 and <= 2048", H);
+  return NBEST_OK;
+}
+
+static int finalize(const float* part, int nblk, int N, float* o0, int a0, float* o1, int a1, float* o2, int a2,
+                    hipStream_t st) {
+  RowredOut o;
+  o.out[0] = o0; o.out[1] = o1; o.out[2] = o2;
+  o.accumulate[0] = a0; o.accumulate[1] = a1; o.accumulate[2] = a2;
+  const int nout = o2 ? 3 : (o1 ? 2 : 1);
+  rowred_finalize_kernel<<<dim3((N + 63) / 64, nout), dim3(64, 4), 0, st>>>(part, nblk, N, o);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+}  // namespace
+
+extern "C" size_t nbest_rowred_ws_bytes(int64_t M, int64_t N) { return (size_t)3 * rowred_blocks(M) * N * sizeof(float); }
+extern "C" size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H) {
+  return nbest_rowred_ws_bytes(M, H) + (size_t)M * H * sizeof(float);
+}
+
+extern "C" int nbest_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                   int64_t M, int H, float eps, int dtype, nbest_stream_t stream) {
+  if (int e = check_h(H)) return e;
+  NB_CHECK(x && gamma && beta && y && stats && M > 0, NBEST_ERR_ARG, "layernorm_fwd: null pointer or M <= 0");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_rows(M, 4);
+  if (dtype == NBEST_F32) {
+    DISPATCH_VPL(H, (ln_fwd_kernel<float, VPL><<<grid, 256, 0, st>>>((const float*)x, gamma, beta, (float*)y, stats, M, H, eps)));
+  } else if (dtype == NBEST_BF16) {
+    DISPATCH_VPL(H, (ln_fwd_kernel<bf16, VPL><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, H, eps)));
+  } else NB_CHECK(false, NBEST_ERR_DTYPE, "layernorm_fwd: bad dtype %d", dtype);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                                   void* dx_drop, float* dgamma, float* dbeta, float* dbias, int64_t M, int H, int dtype,
+                                   int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
+                                   size_t ws_bytes, nbest_stream_t stream) {
+  if (int e = check_h(H)) return e;
+  NB_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && ws && M > 0, NBEST_ERR_ARG, "layernorm_bwd: null pointer");
+  NB_CHECK(ws_bytes >= nbest_rowred_ws_bytes(M, H), NBEST_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
+  const DropCfg d = make_drop(drop_p, seed, drop_stream);
+  NB_CHECK(d.thr16 == 0 || (dx_drop && dx_drop != dx), NBEST_ERR_ARG, "layernorm_bwd: dropout needs a separate dx_drop buffer");
+  NB_CHECK(M * (int64_t)H < (int64_t)1 << 32 || d.thr16 == 0, NBEST_ERR_SHAPE, "layernorm_bwd: dropout counter overflow");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = rowred_blocks(M);
+  const int rpb = (int)((M + nblk - 1) / nblk);
+  float* part = (float*)ws;
+  const size_t smem = (size_t)3 * H * sizeof(float);
+  const int wb = dbias ? 1 : 0;
+  if (dtype == NBEST_F32) {
+    DISPATCH_VPL(H, (ln_bwd_kernel<float, VPL><<<nblk, 256, smem, st>>>((const float*)dy, (const float*)x, stats, gamma,
+                                                                         (float*)dx, (float*)dx_drop, part, M, H, rpb, wb, d)));
+  } else if (dtype == NBEST_BF16) {
+    DISPATCH_VPL(H, (ln_bwd_kernel<bf16, VPL><<<nblk, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, stats, gamma,
+                                                                        (bf16*)dx, (bf16*)dx_drop, part, M, H, rpb, wb, d)));
+  } else NB_CHECK(false, NBEST_ERR_DTYPE, "layernorm_bwd: bad dtype %d", dtype);
+  NB_LAUNCH_CHECK();
+  return finalize(part, nblk, H, dgamma, accumulate, dbeta, accumulate, dbias, accumulate, st);
+}
+
+extern "C" int nbest_colsum(const void* X, float* out, int64_t M, int64_t N, int64_t ld, int dtype, int accumulate,
+                            void* ws, size_t ws_bytes, nbest_stream_t stream) {
+  NB_CHECK(X && out && ws && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, NBEST_ERR_ARG, "colsum: bad arguments");
+  NB_CHECK(ws_bytes >= nbest_rowred_ws_bytes(M, N), NBEST_ERR_WORKSPACE, "colsum: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = rowred_blocks(M);
+  const int rpb = (int)((M + nblk - 1) / nblk);
+  float* part = (float*)ws;
+  dim3 grid((unsigned)((N + 255) / 256), nblk);
+  if (dtype == NBEST_F32) colsum_kernel<float><<<grid, 256, 0, st>>>((const float*)X, part, M, N, ld, rpb);
+  else if (dtype == NBEST_BF16) colsum_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)X, part, M, N, ld, rpb);
+  else NB_CHECK(false, NBEST_ERR_DTYPE, "colsum: bad dtype %d", dtype);
+  NB_LAUNCH_CHECK();
+  return finalize(part, nblk, (int)N, out, accumulate, nullptr, 0, nullptr, 0, st);
+}
+
+extern "C" int nbest_embed_ln_fwd(const int64_t* ids, const int64_t* seg, const int64_t* pos, const void* word,
+                                  const void* type, const void* ptab, const float* gamma, const float* beta, void* out,
+                                  float* stats, int64_t M, int H, float eps, int dtype, float drop_p, uint64_t seed,
+                                  uint32_t drop_stream, nbest_stream_t stream) {
+  if (int e = check_h(H)) return e;
+  NB_CHECK(ids && pos && word && type && ptab && gamma && beta && out && stats && M > 0, NBEST_ERR_ARG, "embed_ln_fwd: null pointer");
+  NB_CHECK(M * (int64_t)H < (int64_t)1 << 32, NBEST_ERR_SHAPE, "embed_ln_fwd: M*H must fit 32 bits (dropout counter)");
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg d = make_drop(drop_p, seed, drop_stream);
+  const int grid = grid_rows(M, 4);
+  if (dtype == NBEST_F32) {
+    DISPATCH_VPL(H, (embed_fwd_kernel<float, VPL><<<grid, 256, 0, st>>>(ids, seg, pos, (const float*)word, (const float*)type,
+                                                                        (const float*)ptab, gamma, beta, (float*)out, stats, M, H, eps, d)));
+  } else if (dtype == NBEST_BF16) {
+    DISPATCH_VPL(H, (embed_fwd_kernel<bf16, VPL><<<grid, 256, 0, st>>>(ids, seg, pos, (const bf16*)word, (const bf16*)type,
+                                                                       (const bf16*)ptab, gamma, beta, (bf16*)out, stats, M, H, eps, d)));
+  } else NB_CHECK(false, NBEST_ERR_DTYPE, "embed_ln_fwd: bad dtype %d", dtype);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const int64_t* pos, const void* word,
+                                  const void* type, const void* ptab, const float* gamma, const float* stats,
+                                  const void* dout, float* dword, float* dtype_tab, float* dptab, float* dgamma,
+                                  float* dbeta, int B, int S, int H, int n_types, int dtype, int64_t word_pad_id,
+                                  int64_t pos_pad_id, int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream,
+                                  void* ws, size_t ws_bytes, nbest_stream_t stream) {
+  if (int e = check_h(H)) return e;
+  const int64_t M = (int64_t)B * S;
+  NB_CHECK(ids && pos && word && type && ptab && gamma && stats && dout && dword && dtype_tab && dptab && dgamma && dbeta && ws && M > 0,
+           NBEST_ERR_ARG, "embed_ln_bwd: null pointer");
+  NB_CHECK(ws_bytes >= nbest_embed_bwd_ws_bytes(M, H), NBEST_ERR_WORKSPACE, "embed_ln_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg d = make_drop(drop_p, seed, drop_stream);
+  const int nblk = rowred_blocks(M);
+  const int rpb = (int)((M + nblk - 1) / nblk);
+  float* part = (float*)ws;
+  float* de_buf = (float*)((char*)ws + nbest_rowred_ws_bytes(M, H));
+  const size_t smem = (size_t)2 * H * sizeof(float);
+  if (dtype == NBEST_F32) {
+    DISPATCH_VPL(H, (embed_bwd_kernel<float, VPL><<<nblk, 256, smem, st>>>(ids, seg, pos, (const float*)word, (const float*)type,
+                                                                            (const float*)ptab, gamma, stats, (const float*)dout, dword,
+                                                                            de_buf, part, M, H, rpb, word_pad_id, d)));
+  } else if (dtype == NBEST_BF16) {
+    DISPATCH_VPL(H, (embed_bwd_kernel<bf16, VPL><<<nblk, 256, smem, st>>>(ids, seg, pos, (const bf16*)word, (const bf16*)type,
+                                                                           (const bf16*)ptab, gamma, stats, (const bf16*)dout, dword,
+                                                                           de_buf, part, M, H, rpb, word_pad_id, d)));
+  } else NB_CHECK(false, NBEST_ERR_DTYPE, "embed_ln_bwd: bad dtype %d", dtype);
+  NB_LAUNCH_CHECK();
+  if (int e = finalize(part, nblk, H, dgamma, accumulate, dbeta, accumulate, nullptr, 0, st)) return e;
+  embed_bwd_tables_kernel<<<S, 256, 0, st>>>(seg, pos, de_buf, dtype_tab, dptab, B, S, H, n_types, pos_pad_id);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_cls_grad_scatter(const float* dcls, void* dhidden, int B, int S, int H, int dtype,
+                                      nbest_stream_t stream) {
+  if (int e = check_h(H)) return e;
+  NB_CHECK(dcls && dhidden && B > 0 && S > 0, NBEST_ERR_ARG, "cls_grad_scatter: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nv = (int64_t)B * S * (H >> 2);
+  int grid = (int)((nv + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (dtype == NBEST_F32) cls_scatter_kernel<float><<<grid, 256, 0, st>>>(dcls, (float*)dhidden, nv, S, H);
+  else if (dtype == NBEST_BF16) cls_scatter_kernel<bf16><<<grid, 256, 0, st>>>(dcls, (bf16*)dhidden, nv, S, H);
+  else NB_CHECK(false, NBEST_ERR_DTYPE, "cls_grad_scatter: bad dtype %d", dtype);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_cast_f32_to_bf16(const float* src, void* dst, int64_t n, nbest_stream_t stream) {
+  NB_CHECK(src && dst && n >= 0, NBEST_ERR_ARG, "cast: bad arguments");
+  if (n == 0) return NBEST_OK;
+  int64_t g = ((n >> 3) + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  cast_bf16_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>(src, (bf16*)dst, n);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}

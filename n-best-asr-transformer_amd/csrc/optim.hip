@@ -1,0 +1,133 @@
+// K9 multi-tensor BertAdam over flat fp32 arenas (p, g, m, v) + bf16 compute-copy refresh.
+// Restates /root/reference/models/optimization.py:237-302 under the per-parameter grouping of
+// /root/reference/n_best_asr_bert.py:540-561 (each tensor clipped on its own to L2 norm 1.0).
+//
+// HBM-bound: phase 1 reads g (4 B/param) for the per-tensor norms, phase 3 reads p,g,m,v and writes
+// p,m,v (+2 B bf16 copy) = 30 B/param.  All tensors are processed by ONE launch per phase: the block
+// -> (tensor, chunk) map is a binary search over desc.block_start (tensors ordered by offset).
+#include "common.h"
+
+namespace {
+
+constexpr int kChunk = 16384;  // elements per block: 256 threads x 16 float4
+
+__device__ __forceinline__ int find_tensor(const nbest_tensor_desc* __restrict__ d, int n, int blk) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].block_start <= blk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const nbest_tensor_desc* __restrict__ descs,
+                                                    int n_tensors, float* __restrict__ partial) {
+  __shared__ float sm[16];
+  const int t = find_tensor(descs, n_tensors, blockIdx.x);
+  const nbest_tensor_desc d = descs[t];
+  float s = 0.f;
+  if (d.active) {
+    const int64_t c0 = (int64_t)(blockIdx.x - d.block_start) * kChunk;
+    const int64_t c1 = (c0 + kChunk < d.numel) ? c0 + kChunk : d.numel;
+    const float* gp = g + d.offset;
+    const bool vec = ((d.offset & 3) == 0);
+    if (vec) {
+      const int64_t v1 = c0 + ((c1 - c0) & ~(int64_t)3);
+      for (int64_t i = c0 + 4 * threadIdx.x; i < v1; i += 1024) {
+        f32x4 x = *(const f32x4*)(gp + i);
+        s += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+      }
+      for (int64_t i = v1 + threadIdx.x; i < c1; i += 256) s += gp[i] * gp[i];
+    } else {
+      for (int64_t i = c0 + threadIdx.x; i < c1; i += 256) s += gp[i] * gp[i];
+    }
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// one wave per tensor: coef[t] = min(1, max_norm / (||g_t|| + 1e-6))
+__global__ __launch_bounds__(64) void clip_coef_kernel(const float* __restrict__ partial, const nbest_tensor_desc* __restrict__ descs,
+                                                       int n_tensors, int n_blocks, float max_norm, float* __restrict__ coef) {
+  const int t = blockIdx.x;
+  const int b0 = descs[t].block_start;
+  const int b1 = (t + 1 < n_tensors) ? descs[t + 1].block_start : n_blocks;
+  float s = 0.f;
+  for (int b = b0 + threadIdx.x; b < b1; b += 64) s += partial[b];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    float c = 1.f;
+    if (max_norm > 0.f) c = fminf(max_norm / (sqrtf(s) + 1e-6f), 1.0f);
+    coef[t] = c;
+  }
+}
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float coef, float b1, float b2, float eps,
+                                      float lr, float wd) {
+  g *= coef;
+  m = m * b1 + (1.f - b1) * g;
+  v = v * b2 + (1.f - b2) * g * g;
+  float u = m / (sqrtf(v) + eps);
+  if (wd > 0.f) u += wd * p;
+  p -= lr * u;
+}
+
+__global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, bf16* __restrict__ plow,
+                                                       const nbest_tensor_desc* __restrict__ descs, int n_tensors,
+                                                       const float* __restrict__ coef, float lr_mult, float b1, float b2, float eps) {
+  const int t = find_tensor(descs, n_tensors, blockIdx.x);
+  const nbest_tensor_desc d = descs[t];
+  if (!d.active) return;
+  const float cf = coef[t];
+  const float lr = d.lr * lr_mult;
+  const int64_t c0 = (int64_t)(blockIdx.x - d.block_start) * kChunk;
+  const int64_t c1 = (c0 + kChunk < d.numel) ? c0 + kChunk : d.numel;
+  const int64_t base = d.offset;
+  const bool vec = ((base & 3) == 0);
+  int64_t v1 = c0;
+  if (vec) {
+    v1 = c0 + ((c1 - c0) & ~(int64_t)3);
+    for (int64_t i = c0 + 4 * threadIdx.x; i < v1; i += 1024) {
+      f32x4 pp = *(f32x4*)(p + base + i), gg = *(const f32x4*)(g + base + i);
+      f32x4 mm = *(f32x4*)(m + base + i), vv = *(f32x4*)(v + base + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float p1 = pp[e], m1 = mm[e], v1e = vv[e];
+        adam1(p1, gg[e], m1, v1e, cf, b1, b2, eps, lr, d.wd);
+        pp[e] = p1; mm[e] = m1; vv[e] = v1e;
+      }
+      *(f32x4*)(p + base + i) = pp;
+      *(f32x4*)(m + base + i) = mm;
+      *(f32x4*)(v + base + i) = vv;
+      if (plow) Vec4<bf16>::store(plow + base + i, pp);
+    }
+  }
+  for (int64_t i = v1 + threadIdx.x; i < c1; i += 256) {
+    float pp = p[base + i], mm = m[base + i], vv = v[base + i];
+    adam1(pp, g[base + i], mm, vv, cf, b1, b2, eps, lr, d.wd);
+    p[base + i] = pp; m[base + i] = mm; v[base + i] = vv;
+    if (plow) plow[base + i] = (bf16)pp;
+  }
+}
+
+}  // namespace
+
+extern "C" int nbest_bertadam_chunk(void) { return kChunk; }
+
+extern "C" int nbest_bertadam_step(float* p, float* g, float* m, float* v, void* p_lowp, const nbest_tensor_desc* descs,
+                                   int n_tensors, int n_blocks, float lr_mult, float b1, float b2, float eps, float max_grad_norm,
+                                   void* ws, size_t ws_bytes, nbest_stream_t stream) {
+  NB_CHECK(p && g && m && v && descs && ws && n_tensors > 0 && n_blocks > 0, NBEST_ERR_ARG, "bertadam: null pointer");
+  NB_CHECK(ws_bytes >= ((size_t)n_blocks + n_tensors) * sizeof(float), NBEST_ERR_WORKSPACE, "bertadam: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  float* coef = partial + n_blocks;
+  sumsq_kernel<<<n_blocks, 256, 0, st>>>(g, descs, n_tensors, partial);
+  NB_LAUNCH_CHECK();
+  clip_coef_kernel<<<n_tensors, 64, 0, st>>>(partial, descs, n_tensors, n_blocks, max_grad_norm, coef);
+  NB_LAUNCH_CHECK();
+  bertadam_kernel<<<n_blocks, 256, 0, st>>>(p, g, m, v, (bf16*)p_lowp, descs, n_tensors, coef, lr_mult, b1, b2, eps);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}

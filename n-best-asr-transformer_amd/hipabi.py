@@ -1,0 +1,311 @@
+"""ctypes binding of the C-ABI library ``csrc/libnbest_hip.so`` (declared in include/nbest_hip.h).
+
+PyTorch is used only for device memory and streams: every wrapper passes ``tensor.data_ptr()`` and
+the current HIP stream handle.  There is NO fallback: if the library is missing or an entry point
+fails, a RuntimeError is raised (the product path must never silently run on the CPU).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnbest_hip.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_DGELU, EPI_RES, EPI_F32_SPLITK = range(7)
+
+EXPORTS = [
+    "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes",
+    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_layernorm_fwd",
+    "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
+    "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step",
+    "nbest_cast_f32_to_bf16", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
+    "nbest_encoder_backward",
+]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+                ("U", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64), ("ldu", C.c_int64),
+                ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("dtype", C.c_int32),
+                ("accumulate", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class LabelSpaceC(C.Structure):
+    _fields_ = [("n_top", C.c_int32), ("n_bottom", C.c_int32), ("n_rows", C.c_int32),
+                ("bottom_off", C.c_void_p), ("bottom_ids", C.c_void_p), ("head_row", C.c_void_p)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("lr", C.c_float), ("wd", C.c_float),
+                ("active", C.c_int32), ("block_start", C.c_int32)]
+
+
+class LayerOffsets(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")]
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("L", C.c_int32),
+                ("heads", C.c_int32), ("F", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("n_types", C.c_int32),
+                ("ln_eps", C.c_float), ("hidden_drop", C.c_float), ("attn_drop", C.c_float),
+                ("word_pad_id", C.c_int64), ("pos_pad_id", C.c_int64),
+                ("off_word", C.c_int64), ("off_pos", C.c_int64), ("off_type", C.c_int64),
+                ("off_emb_ln_g", C.c_int64), ("off_emb_ln_b", C.c_int64),
+                ("layers_host", C.POINTER(LayerOffsets)), ("seed", C.c_uint64), ("drop_stream_base", C.c_uint32),
+                ("pad", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the library once; fail loudly when it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("nbest_amd: %s is missing - build it with `make -C %s` (hipcc, gfx950). "
+                               "There is no CPU fallback for the product path." % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        L = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise RuntimeError("nbest_amd: %s does not export %s" % (LIB_PATH, name))
+        for name in ("nbest_embed_bwd_ws_bytes", "nbest_gemm_ws_bytes", "nbest_rowred_ws_bytes", "nbest_heads_ws_bytes",
+                     "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes"):
+            getattr(L, name).restype = C.c_size_t
+        L.nbest_embed_bwd_ws_bytes.argtypes = [C.c_int64, C.c_int64]
+        L.nbest_rowred_ws_bytes.argtypes = [C.c_int64, C.c_int64]
+        L.nbest_heads_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.nbest_gemm_ws_bytes.argtypes = [C.POINTER(GemmArgs)]
+        L.nbest_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        L.nbest_encoder_act_bytes.argtypes = [C.POINTER(EncoderDesc)]
+        L.nbest_encoder_ws_bytes.argtypes = [C.POINTER(EncoderDesc)]
+        vp, i64, i32, f32, u64, u32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
+        L.nbest_embed_ln_fwd.argtypes = [vp] * 10 + [i64, i32, f32, i32, f32, u64, u32, vp]
+        L.nbest_embed_ln_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, i32, i64, i64, i32, f32, u64, u32, vp, sz, vp]
+        L.nbest_attention_fwd.argtypes = [vp] * 4 + [i32] * 5 + [f32, u64, u32, vp]
+        L.nbest_attention_bwd.argtypes = [vp] * 6 + [i32] * 5 + [f32, u64, u32, vp]
+        L.nbest_layernorm_fwd.argtypes = [vp] * 5 + [i64, i32, f32, i32, vp]
+        L.nbest_layernorm_bwd.argtypes = [vp] * 9 + [i64, i32, i32, i32, f32, u64, u32, vp, sz, vp]
+        L.nbest_colsum.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, sz, vp]
+        L.nbest_stc_heads.argtypes = [vp, i64, vp, vp, C.POINTER(LabelSpaceC)] + [vp] * 8 + [i32] * 5 + [f32, u64, u32, vp, sz, vp]
+        L.nbest_cls_mse.argtypes = [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp]
+        L.nbest_cls_grad_scatter.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        L.nbest_stc_decode.argtypes = [vp, vp, C.POINTER(LabelSpaceC), vp, vp, i32, vp]
+        L.nbest_bertadam_step.argtypes = [vp] * 6 + [i32, i32, f32, f32, f32, f32, f32, vp, sz, vp]
+        L.nbest_cast_f32_to_bf16.argtypes = [vp, vp, i64, vp]
+        L.nbest_encoder_forward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 7 + [sz, vp, sz, C.POINTER(C.c_void_p), vp]
+        L.nbest_encoder_backward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 8 + [sz, vp, vp, sz, i32, vp]
+        L.nbest_last_error.argtypes = [C.c_char_p, sz]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().nbest_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("nbest_hip %s failed (%d): %s" % (what, rc, last_error()))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise RuntimeError("nbest_amd: unsupported activation dtype %s" % t)
+
+
+def ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# thin per-op wrappers (used by the kernel parity tests; training goes through encoder_forward/backward)
+# ------------------------------------------------------------------------------------------------
+def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=None, R=None, U=None, out=None,
+         accumulate=False, drop_p=0.0, seed=0, drop_stream=0):
+    """C[M,N] = epi(op(A) . op(B)); returns C (and U for EPI_BIAS_GELU)."""
+    dt = dtype_code(A.dtype)
+    dev = A.device
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32_SPLITK else A.dtype, device=dev)
+    if epilogue == EPI_BIAS_GELU and U is None:
+        U = torch.empty(M, N, dtype=A.dtype, device=dev)
+    g = GemmArgs()
+    g.A, g.B, g.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.R = R.data_ptr() if R is not None else None
+    g.U = U.data_ptr() if U is not None else None
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = A.stride(0), B.stride(0), out.stride(0)
+    g.ldr = R.stride(0) if R is not None else 0
+    g.ldu = U.stride(0) if U is not None else 0
+    g.trans_a, g.trans_b, g.epilogue, g.dtype = int(trans_a), int(trans_b), epilogue, dt
+    g.accumulate, g.drop_p, g.drop_stream, g.seed = int(accumulate), drop_p, drop_stream, seed
+    nb = lib().nbest_gemm_ws_bytes(C.byref(g))
+    ws = _ws(nb, dev)
+    g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
+    check(lib().nbest_gemm(C.byref(g), stream_ptr()), "gemm")
+    return (out, U) if epilogue == EPI_BIAS_GELU else out
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    M, H = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    check(lib().nbest_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), M, H, eps, dtype_code(x.dtype),
+                                    stream_ptr()), "layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(dy, x, stats, gamma, want_dbias=True, drop_p=0.0, seed=0, drop_stream=0):
+    M, H = x.shape
+    dx = torch.empty_like(x)
+    dxd = torch.empty_like(x) if drop_p > 0 else None
+    dg = torch.zeros(H, dtype=torch.float32, device=x.device)
+    db = torch.zeros_like(dg)
+    dbias = torch.zeros_like(dg) if want_dbias else None
+    ws = _ws(lib().nbest_rowred_ws_bytes(M, H), x.device)
+    check(lib().nbest_layernorm_bwd(ptr(dy), ptr(x), ptr(stats), ptr(gamma), ptr(dx), ptr(dxd), ptr(dg), ptr(db), ptr(dbias),
+                                    M, H, dtype_code(x.dtype), 0, drop_p, seed, drop_stream, ptr(ws), ws.numel(), stream_ptr()),
+          "layernorm_bwd")
+    return dx, dxd, dg, db, dbias
+
+
+def colsum(X, accumulate=False, out=None):
+    M, N = X.shape
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=X.device)
+    ws = _ws(lib().nbest_rowred_ws_bytes(M, N), X.device)
+    check(lib().nbest_colsum(ptr(X), ptr(out), M, N, X.stride(0), dtype_code(X.dtype), int(accumulate), ptr(ws), ws.numel(),
+                             stream_ptr()), "colsum")
+    return out
+
+
+def attention_fwd(qkv, key_mask, B, S, heads, drop_p=0.0, seed=0, drop_stream=0):
+    H = heads * 64
+    ctx = torch.empty(B * S, H, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, heads, S, dtype=torch.float32, device=qkv.device)
+    check(lib().nbest_attention_fwd(ptr(qkv), ptr(key_mask), ptr(ctx), ptr(lse), B, S, heads, 64, dtype_code(qkv.dtype),
+                                    drop_p, seed, drop_stream, stream_ptr()), "attention_fwd")
+    return ctx, lse
+
+
+def attention_bwd(qkv, key_mask, ctx, dctx, lse, B, S, heads, drop_p=0.0, seed=0, drop_stream=0):
+    dqkv = torch.empty_like(qkv)
+    check(lib().nbest_attention_bwd(ptr(qkv), ptr(key_mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), B, S, heads, 64,
+                                    dtype_code(qkv.dtype), drop_p, seed, drop_stream, stream_ptr()), "attention_bwd")
+    return dqkv
+
+
+def embed_ln_fwd(ids, seg, pos, word, type_tab, ptab, gamma, beta, eps, drop_p=0.0, seed=0, drop_stream=0):
+    M, H = ids.numel(), word.shape[1]
+    out = torch.empty(M, H, dtype=word.dtype, device=word.device)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=word.device)
+    check(lib().nbest_embed_ln_fwd(ptr(ids), ptr(seg), ptr(pos), ptr(word), ptr(type_tab), ptr(ptab), ptr(gamma), ptr(beta),
+                                   ptr(out), ptr(stats), M, H, eps, dtype_code(word.dtype), drop_p, seed, drop_stream,
+                                   stream_ptr()), "embed_ln_fwd")
+    return out, stats
+
+
+def embed_ln_bwd(ids, seg, pos, word, type_tab, ptab, gamma, stats, dout, B, S, word_pad_id=-1, pos_pad_id=-1, drop_p=0.0,
+                 seed=0, drop_stream=0):
+    H = word.shape[1]
+    dev = word.device
+    dword = torch.zeros(word.shape, dtype=torch.float32, device=dev)
+    dtype_tab = torch.zeros(type_tab.shape, dtype=torch.float32, device=dev)
+    dptab = torch.zeros(ptab.shape, dtype=torch.float32, device=dev)
+    dg = torch.zeros(H, dtype=torch.float32, device=dev)
+    db = torch.zeros_like(dg)
+    ws = _ws(lib().nbest_embed_bwd_ws_bytes(B * S, H), dev)
+    check(lib().nbest_embed_ln_bwd(ptr(ids), ptr(seg), ptr(pos), ptr(word), ptr(type_tab), ptr(ptab), ptr(gamma), ptr(stats),
+                                   ptr(dout), ptr(dword), ptr(dtype_tab), ptr(dptab), ptr(dg), ptr(db), B, S, H,
+                                   type_tab.shape[0], dtype_code(word.dtype), word_pad_id, pos_pad_id, 0, drop_p, seed,
+                                   drop_stream, ptr(ws), ws.numel(), stream_ptr()), "embed_ln_bwd")
+    return dword, dtype_tab, dptab, dg, db
+
+
+class DeviceLabelSpace:
+    """Device copy of the STC label hierarchy in the layout nbest_label_space expects."""
+
+    def __init__(self, labels, device):
+        off, ids, head_row = [0], [], []
+        row = labels.n_top
+        for t in range(labels.n_top):
+            bs = labels.top2bottom[t]
+            ids += bs
+            off.append(len(ids))
+            if len(bs) >= 2:
+                head_row.append(row)
+                row += len(bs)
+            else:
+                head_row.append(-1)
+        self.n_rows = row
+        assert row == labels.n_head_rows
+        self.labels = labels
+        i32 = dict(dtype=torch.int32, device=device)
+        self.bottom_off = torch.tensor(off, **i32)
+        self.bottom_ids = torch.tensor(ids, **i32)
+        self.head_row = torch.tensor(head_row, **i32)
+        self.head_row_host = head_row
+        self.none_flag = torch.tensor([1 if l.endswith("NONE") else 0 for l in labels.idx2label], dtype=torch.uint8, device=device)
+        self.c = LabelSpaceC(labels.n_top, labels.n_bottom, row, self.bottom_off.data_ptr(), self.bottom_ids.data_ptr(),
+                             self.head_row.data_ptr())
+
+
+def stc_heads(hidden, cls_stride, Wh, bh, dls, labels_f, B, H, need_grad=True, accumulate=False, drop_p=0.0, seed=0,
+              drop_stream=0, dWh=None, dbh=None):
+    dev = Wh.device
+    R, nt, nb = dls.n_rows, dls.labels.n_top, dls.labels.n_bottom
+    f = dict(dtype=torch.float32, device=dev)
+    top, bott, fin = torch.empty(B, nt, **f), torch.empty(B, R - nt, **f), torch.empty(B, nb, **f)
+    loss = torch.empty(4, **f)
+    dcls = torch.empty(B, H, **f) if need_grad else None
+    if need_grad and dWh is None:
+        dWh, dbh = torch.zeros(R, H, **f), torch.zeros(R, **f)
+    ws = _ws(lib().nbest_heads_ws_bytes(B, R, H), dev)
+    check(lib().nbest_stc_heads(ptr(hidden), cls_stride, ptr(Wh), ptr(bh), C.byref(dls.c), ptr(labels_f), ptr(top), ptr(bott),
+                                ptr(fin), ptr(loss), ptr(dcls), ptr(dWh), ptr(dbh), B, H, dtype_code(hidden.dtype),
+                                int(need_grad), int(accumulate), drop_p, seed, drop_stream, ptr(ws), ws.numel(), stream_ptr()),
+          "stc_heads")
+    return top, bott, fin, loss, dcls, dWh, dbh
+
+
+def stc_decode(top, bott, dls):
+    B = top.shape[0]
+    pred = torch.empty(B, dls.labels.n_top, dtype=torch.int32, device=top.device)
+    check(lib().nbest_stc_decode(ptr(top), ptr(bott), C.byref(dls.c), ptr(dls.none_flag), ptr(pred), B, stream_ptr()), "stc_decode")
+    return pred
+
+
+def cls_mse(hidden_a, stride_a, hidden_t, stride_t, B, H, da=None, dt=None, grad_scale=1.0):
+    loss = torch.empty(1, dtype=torch.float32, device=hidden_a.device)
+    check(lib().nbest_cls_mse(ptr(hidden_a), stride_a, ptr(hidden_t), stride_t, ptr(loss), ptr(da), ptr(dt), B, H,
+                              dtype_code(hidden_a.dtype), grad_scale, stream_ptr()), "cls_mse")
+    return loss
+
+
+def cls_grad_scatter(dcls, B, S, H, dtype):
+    dh = torch.empty(B * S, H, dtype=dtype, device=dcls.device)
+    check(lib().nbest_cls_grad_scatter(ptr(dcls), ptr(dh), B, S, H, dtype_code(dtype), stream_ptr()), "cls_grad_scatter")
+    return dh
+
+
+def cast_bf16(src, dst):
+    check(lib().nbest_cast_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "cast_f32_to_bf16")

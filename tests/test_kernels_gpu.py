@@ -1,0 +1,298 @@
+"""GPU parity of every hand-written HIP kernel (called through the C-ABI) against a plain PyTorch
+fp32 restatement of the same op on identical seeded inputs.  Tolerances: fp32 path 1e-4 relative to
+the tensor scale (north_star), bf16 path 1e-2 relative to the tensor scale."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import nbest_amd  # noqa: E402,F401
+from nbest_amd import hipabi as hb  # noqa: E402
+
+DEV = "cuda"
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "kernel_parity.log")
+
+
+def _log(msg):
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write(msg + "\n")
+
+
+def close(name, got, ref, tol):
+    got, ref = got.float(), ref.float()
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item() / scale
+    _log("%-58s rel_err=%.3e tol=%.1e scale=%.3e %s" % (name, err, tol, scale, "OK" if err <= tol else "FAIL"))
+    assert math.isfinite(err) and err <= tol, "%s: rel err %.3e > %.1e (scale %.3e)" % (name, err, tol, scale)
+
+
+def rnd(*shape, dtype=torch.float32, s=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * s).to(DEV).to(dtype)
+
+
+def tol_of(dtype):
+    return 1e-4 if dtype == torch.float32 else 1.5e-2
+
+
+def gelu(u):
+    return 0.5 * u * (1 + torch.erf(u / math.sqrt(2)))
+
+
+def dgelu(u):
+    return 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
+def test_gemm_layouts_and_epilogues(dtype, ta, tb):
+    # ragged M for the activation-major GEMMs; ragged K (token dim) for the weight-gradient GEMM
+    M, N, K = (200, 256, 192) if not ta else (256, 128, 1000)
+    A = rnd(K, M, dtype=dtype, seed=1) if ta else rnd(M, K, dtype=dtype, seed=1)
+    B = rnd(K, N, dtype=dtype, seed=2) if tb else rnd(N, K, dtype=dtype, seed=2)
+    Af = (A.float().t() if ta else A.float())
+    Bf = (B.float() if tb else B.float().t())
+    ref = Af @ Bf
+    tol = tol_of(dtype)
+    tag = "gemm[%s ta=%d tb=%d]" % (str(dtype)[6:], ta, tb)
+    close(tag + " none", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_NONE), ref, tol)
+    bias = rnd(N, seed=3)
+    close(tag + " bias", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_BIAS, bias=bias), ref + bias, tol)
+    out, U = hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_BIAS_GELU, bias=bias)
+    close(tag + " bias_gelu.U", U, ref + bias, tol)
+    close(tag + " bias_gelu.C", out, gelu(ref + bias), tol)
+    R = rnd(M, N, dtype=dtype, seed=4)
+    close(tag + " bias_res", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_BIAS_DROP_RES, bias=bias, R=R), ref + bias + R.float(), tol)
+    close(tag + " res", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_RES, R=R), ref + R.float(), tol)
+    Uin = rnd(M, N, dtype=dtype, seed=5)
+    close(tag + " dgelu", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_DGELU, U=Uin), ref * dgelu(Uin.float()), tol)
+    got = hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_F32_SPLITK)
+    assert got.dtype == torch.float32
+    close(tag + " f32_splitk", got, ref, tol)
+    acc = got.clone()
+    hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_F32_SPLITK, out=acc, accumulate=True)
+    close(tag + " f32_splitk+acc", acc, 2 * ref, tol)
+
+
+def test_gemm_bf16_bert_shapes():
+    """the real layer shapes at a ragged token count (M = 3*128+40)"""
+    M, H, F = 424, 768, 3072
+    x = rnd(M, H, dtype=torch.bfloat16, seed=11)
+    for (N, K, seed) in [(3 * H, H, 12), (H, H, 13), (F, H, 14), (H, F, 15)]:
+        A = x if K == H else rnd(M, K, dtype=torch.bfloat16, seed=seed + 50)
+        W = rnd(N, K, dtype=torch.bfloat16, s=0.05, seed=seed)
+        close("gemm bert fwd N=%d K=%d" % (N, K), hb.gemm(A, W, M, N, K), A.float() @ W.float().t(), 1.5e-2)
+        dY = rnd(M, N, dtype=torch.bfloat16, seed=seed + 20)
+        close("gemm bert dgrad N=%d K=%d" % (N, K), hb.gemm(dY, W, M, K, N, 0, 1), dY.float() @ W.float(), 1.5e-2)
+        close("gemm bert wgrad N=%d K=%d" % (N, K), hb.gemm(dY, A, N, K, M, 1, 1, hb.EPI_F32_SPLITK),
+              dY.float().t() @ A.float(), 1.5e-2)
+
+
+def test_gemm_dropout_mask_is_shared_with_layernorm_bwd():
+    M, N, K, p = 256, 256, 64, 0.25
+    A = rnd(M, K, dtype=torch.bfloat16, seed=21)
+    B = rnd(N, K, dtype=torch.bfloat16, seed=22)
+    bias = torch.zeros(N, device=DEV)
+    R = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    y0 = hb.gemm(A, B, M, N, K, epilogue=hb.EPI_BIAS_DROP_RES, bias=bias, R=R).float()
+    y = hb.gemm(A, B, M, N, K, epilogue=hb.EPI_BIAS_DROP_RES, bias=bias, R=R, drop_p=p, seed=7, drop_stream=3).float()
+    dropped = (y == 0) & (y0 != 0)
+    frac = dropped.float().mean().item()
+    assert abs(frac - p) < 0.02, frac
+    kept = ~dropped & (y0 != 0)
+    p_eff = round(p * 65536) / 65536
+    close("dropout survivors scaled", y[kept], y0[kept] / (1 - p_eff), 2e-2)
+    # LN backward regenerates the same mask for the dense-branch gradient
+    x = rnd(M, N, dtype=torch.bfloat16, seed=23)
+    g = torch.ones(N, device=DEV)
+    _, stats = hb.layernorm_fwd(x, g, torch.zeros(N, device=DEV), 1e-12)
+    dy = rnd(M, N, dtype=torch.bfloat16, seed=24)
+    dx, dxd, *_ = hb.layernorm_bwd(dy, x, stats, g, drop_p=p, seed=7, drop_stream=3)
+    assert torch.equal((dxd.float() == 0) & (dx.float() != 0), dropped & (dx.float() != 0))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H", [(37, 768), (300, 1024), (64, 128)])
+def test_layernorm_fwd_bwd(dtype, M, H):
+    x = rnd(M, H, dtype=dtype, seed=31)
+    g, b = 1 + 0.1 * rnd(H, seed=32), 0.1 * rnd(H, seed=33)
+    y, stats = hb.layernorm_fwd(x, g, b, 1e-12)
+    xr = x.float().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (H,), g, b, 1e-12)
+    tol = tol_of(dtype)
+    close("ln_fwd %s %dx%d" % (dtype, M, H), y, yr, tol)
+    dy = rnd(M, H, dtype=dtype, seed=34)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr2 = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-12)
+    yr2.backward(dy.float())
+    dx, _, dg, db, dbias = hb.layernorm_bwd(dy, x, stats, g)
+    close("ln_bwd dx", dx, xr.grad, tol)
+    close("ln_bwd dgamma", dg, gr.grad, 5 * tol)
+    close("ln_bwd dbeta", db, br.grad, 5 * tol)
+    close("ln_bwd dbias", dbias, dx.float().sum(0), 5 * tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum(dtype):
+    X = rnd(1000, 2304, dtype=dtype, seed=41)
+    close("colsum", hb.colsum(X), X.float().sum(0), 2e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_fwd_bwd(dtype):
+    B, S, H, V = 3, 40, 768, 500
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(2, V, (B, S), generator=g).to(DEV)
+    ids[1, 30:] = 0
+    ids[2, 20:] = 0                                          # padding rows (row 0 = padding_idx: no gradient)
+    seg = (torch.arange(S)[None, :] > 12).long().expand(B, S).contiguous().to(DEV)
+    pos = torch.arange(S)[None, :].expand(B, S).contiguous().to(DEV)
+    word, tt, pt = rnd(V, H, dtype=dtype, s=0.5, seed=51), rnd(2, H, dtype=dtype, s=0.5, seed=52), rnd(64, H, dtype=dtype, s=0.5, seed=53)
+    gam, bet = 1 + 0.1 * rnd(H, seed=54), 0.1 * rnd(H, seed=55)
+    out, stats = hb.embed_ln_fwd(ids, seg, pos, word, tt, pt, gam, bet, 1e-12)
+    wr, tr, pr = (t.float().clone().requires_grad_(True) for t in (word, tt, pt))
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    e = torch.nn.functional.embedding(ids, wr, padding_idx=0) + tr[seg] + pr[pos]
+    ref = torch.nn.functional.layer_norm(e, (H,), gr, br, 1e-12).reshape(B * S, H)
+    tol = tol_of(dtype)
+    close("embed_fwd", out, ref, tol)
+    dout = rnd(B * S, H, dtype=dtype, seed=56)
+    ref.backward(dout.float())
+    dword, dtt, dpt, dg, db = hb.embed_ln_bwd(ids, seg, pos, word, tt, pt, gam, stats, dout, B, S, word_pad_id=0)
+    close("embed_bwd dword", dword, wr.grad, 5 * tol)
+    close("embed_bwd dtype", dtt, tr.grad, 5 * tol)
+    close("embed_bwd dpos", dpt, pr.grad, 5 * tol)
+    close("embed_bwd dgamma", dg, gr.grad, 5 * tol)
+    close("embed_bwd dbeta", db, br.grad, 5 * tol)
+    assert dword[0].abs().max().item() == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, mask, B, S, heads):
+    H = heads * 64
+    q, k, v = qkv.float().reshape(B, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    sc = q @ k.transpose(-1, -2) / 8.0
+    sc = sc.masked_fill(~mask.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(sc, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * S, H), torch.logsumexp(sc, -1)
+
+
+@pytest.mark.parametrize("dtype,S", [(torch.float32, 48), (torch.float32, 37), (torch.bfloat16, 128), (torch.bfloat16, 48),
+                                     (torch.bfloat16, 37), (torch.bfloat16, 96)])
+def test_attention_fwd_bwd(dtype, S):
+    B, heads = 3, 4
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, dtype=dtype, s=1.0, seed=61)
+    mask = torch.ones(B, S, dtype=torch.uint8, device=DEV)
+    mask[1, S - 9:] = 0
+    mask[2, S // 2:] = 0
+    ctx, lse = hb.attention_fwd(qkv, mask, B, S, heads)
+    qr = qkv.float().clone().requires_grad_(True)
+    ref, lse_ref = _attn_ref(qr, mask, B, S, heads)
+    tol = tol_of(dtype)
+    close("attn_fwd ctx %s S=%d" % (dtype, S), ctx, ref, tol)
+    close("attn_fwd lse", lse, lse_ref, tol)
+    dctx = rnd(B * S, H, dtype=dtype, seed=62)
+    ref.backward(dctx.float())
+    dqkv = hb.attention_bwd(qkv, mask, ctx, dctx, lse, B, S, heads)
+    d, r = dqkv.float().reshape(B * S, 3, H), qr.grad.reshape(B * S, 3, H)
+    for i, nm in enumerate("QKV"):
+        close("attn_bwd d%s %s S=%d" % (nm, dtype, S), d[:, i], r[:, i], 2 * tol)
+
+
+@pytest.mark.parametrize("S", [160, 256])
+def test_attention_fwd_bf16_long(S):
+    B, heads = 2, 12
+    qkv = rnd(B * S, 3 * heads * 64, dtype=torch.bfloat16, seed=63)
+    mask = torch.ones(B, S, dtype=torch.uint8, device=DEV)
+    mask[1, S - 30:] = 0
+    ctx, lse = hb.attention_fwd(qkv, mask, B, S, heads)
+    ref, lse_ref = _attn_ref(qkv, mask, B, S, heads)
+    close("attn_fwd bf16 S=%d" % S, ctx, ref, 1.5e-2)
+    close("attn_fwd bf16 lse S=%d" % S, lse, lse_ref, 1.5e-2)
+
+
+def test_attention_dropout_fwd_bwd_consistent():
+    """bf16 MFMA and fp32 VALU kernels must draw the SAME mask from (seed, stream); the backward of
+    each must be the gradient of its own forward (checked through the fp32 kernel by finite differences
+    on a linear functional)."""
+    B, S, heads, p = 2, 64, 2, 0.2
+    H = heads * 64
+    qkv32 = rnd(B * S, 3 * H, seed=71)
+    mask = torch.ones(B, S, dtype=torch.uint8, device=DEV)
+    c32, l32 = hb.attention_fwd(qkv32, mask, B, S, heads, drop_p=p, seed=5, drop_stream=9)
+    c16, l16 = hb.attention_fwd(qkv32.bfloat16(), mask, B, S, heads, drop_p=p, seed=5, drop_stream=9)
+    close("attn dropout bf16 vs f32 fwd", c16, c32, 3e-2)
+    w = rnd(B * S, H, seed=72)
+    dq = hb.attention_bwd(qkv32, mask, c32, w, l32, B, S, heads, drop_p=p, seed=5, drop_stream=9)
+    dirn = rnd(B * S, 3 * H, seed=73)
+    eps = 1e-2
+    cp, _ = hb.attention_fwd(qkv32 + eps * dirn, mask, B, S, heads, drop_p=p, seed=5, drop_stream=9)
+    cm, _ = hb.attention_fwd(qkv32 - eps * dirn, mask, B, S, heads, drop_p=p, seed=5, drop_stream=9)
+    fd = ((cp - cm) * w).sum().item() / (2 * eps)
+    an = (dq * dirn).sum().item()
+    _log("attn dropout finite-difference %.6f vs analytic %.6f" % (fd, an))
+    assert abs(fd - an) <= 2e-2 * max(1.0, abs(fd))
+    dq16 = hb.attention_bwd(qkv32.bfloat16(), mask, c16, w.bfloat16(), l16, B, S, heads, drop_p=p, seed=5, drop_stream=9)
+    close("attn dropout bf16 vs f32 bwd", dq16, dq, 4e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_stc_heads_loss_and_grads_match_oracle(labels):
+    from oracle import stc
+    B, H = 6, 768
+    g = torch.Generator().manual_seed(3)
+    hidden = torch.randn(B, 5, H, generator=g)                 # CLS row = [:,0,:]
+    heads = stc.OracleHeads(labels.top2bottom, H, labels.n_bottom, 0.0)
+    for p_ in heads.parameters():
+        torch.nn.init.normal_(p_, std=0.05, generator=g)
+    y = torch.zeros(B, labels.n_bottom)
+    for b in range(B):
+        for t in torch.randperm(labels.n_top, generator=g)[:2].tolist():
+            bs = labels.top2bottom[t]
+            y[b, bs[int(torch.randint(0, len(bs), (1,), generator=g))]] = 1
+    cls = hidden[:, 0, :].clone().requires_grad_(True)
+    top, bottoms, final = heads(cls)
+    b2t = stc.bottom2top_matrix(labels.top2bottom)
+    rec, total, parts = stc.total_loss(top, bottoms, final, y, labels.top2bottom, b2t)
+    total.backward()
+    dls = hb.DeviceLabelSpace(labels, DEV)
+    Wh = torch.cat([heads.top_linear_layer.weight] + [heads.linear_layers["lin_%d" % t].weight for t in labels.multi]).detach().to(DEV)
+    bh = torch.cat([heads.top_linear_layer.bias] + [heads.linear_layers["lin_%d" % t].bias for t in labels.multi]).detach().to(DEV)
+    hd = hidden.to(DEV).reshape(B * 5, H).contiguous()
+    gtop, gbott, gfin, gloss, dcls, dWh, dbh = hb.stc_heads(hd, 5 * H, Wh.contiguous(), bh.contiguous(), dls, y.to(DEV), B, H)
+    close("heads top", gtop.cpu(), top, 1e-5)
+    close("heads bott", gbott.cpu(), torch.cat([bottoms["lin_%d" % t] for t in labels.multi], 1), 1e-5)
+    close("heads final", gfin.cpu(), final, 1e-5)
+    close("heads loss parts", gloss[:3].cpu(), torch.stack([parts["bottom_bce"], parts["top_bce"], parts["ce"]]).detach(), 1e-5)
+    close("heads dcls", dcls.cpu(), cls.grad, 1e-4)
+    dW_ref = torch.cat([heads.top_linear_layer.weight.grad] + [heads.linear_layers["lin_%d" % t].weight.grad for t in labels.multi])
+    db_ref = torch.cat([heads.top_linear_layer.bias.grad] + [heads.linear_layers["lin_%d" % t].bias.grad for t in labels.multi])
+    close("heads dW", dWh.cpu(), dW_ref, 1e-4)
+    close("heads db", dbh.cpu(), db_ref, 1e-4)
+    pred = hb.stc_decode(gtop, gbott, dls).cpu()
+    ref_dec = stc.decode_indices(top.detach(), {k: v.detach() for k, v in bottoms.items()}, labels.top2bottom, labels.idx2label)
+    assert torch.equal(pred.long(), ref_dec)                   # bit-exact label indices
+
+
+def test_cls_mse():
+    B, S, H = 4, 6, 768
+    a, t = rnd(B * S, H, seed=81), rnd(B * 3, H, seed=82)
+    da = torch.zeros(B, H, device=DEV)
+    dt = torch.zeros(B, H, device=DEV)
+    loss = hb.cls_mse(a, S * H, t, 3 * H, B, H, da, dt)
+    ar = a.reshape(B, S, H)[:, 0].clone().requires_grad_(True)
+    tr = t.reshape(B, 3, H)[:, 0].clone().requires_grad_(True)
+    ref = torch.nn.functional.mse_loss(ar, tr)
+    ref.backward()
+    close("mse loss", loss, ref.detach().reshape(1), 1e-5)
+    close("mse da", da, ar.grad, 1e-5)
+    close("mse dt", dt, tr.grad, 1e-5)
