@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fine-tuning throughput (utterances/s) of the HIP hot path on synthetic n-best
+sequences - BASELINE.json configs[1]: bert-base-uncased shape, bf16, n_best=5, seq_len=128, batch 256 per
+GPU; one process per GPU (torchrun), data-parallel over RCCL, weak scaling.
+
+A step = forward (embeddings, 12 layers, STC heads + losses) + backward + gradient all-reduce +
+BertAdam (per-tensor clip) with dropout ON (hidden 0.1, attention 0.1, heads 0.3, the shipped script's
+values).  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import nbest_amd  # noqa: F401
+from nbest_amd import config as ncfg, synth, hipabi as hb
+from nbest_amd.model import NBestSTCModel
+from nbest_amd.optim import HipBertAdam
+from nbest_amd.trainer import GradReducer, broadcast_parameters, init_distributed, train_step
+
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X (MI355X_MICROARCH.md)
+
+
+def flops_per_utt(cfg, S, St=0):
+    """3 x L*S*(24 H^2 + 4 S H) (+ the transcript pass when --add_l2_loss)"""
+    H, L = cfg.hidden_size, cfg.num_hidden_layers
+    f = lambda s: L * s * (24 * H * H + 4 * s * H)
+    return 3.0 * (f(S) + (f(St) if St else 0))
+
+
+def cpu_baseline(labels, seconds_budget=25.0):
+    """the oracle (CPU restatement, kind "port") timed on this box's host cores at BASELINE configs[0]'s
+    shape: bert-base fp32, B=8, S=128, n_best=5: forward + losses + backward + BertAdam."""
+    from oracle.encoder import EncoderConfig as OCfg
+    from oracle.model import OracleModel
+    from oracle.bertadam import OracleBertAdam
+    from oracle.step import train_step as oracle_step
+    from oracle import stc
+    # the GPU box reports the host's cores but grants a 16-core share per GPU: more threads than that thrash
+    cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
+    torch.set_num_threads(cores)
+    cfg = ncfg.bert_base()
+    ocfg = OCfg(**{k: v for k, v in cfg.to_dict().items() if k in OCfg.__dataclass_fields__})
+    torch.manual_seed(999)
+    om = OracleModel(ocfg, labels.top2bottom, labels.n_bottom, 0.3)
+    om.train()
+    b = synth.nbest_batch(cfg, labels, 8, 128, n_best=5, seed=999)
+    t = {k: torch.from_numpy(v) for k, v in b.items()}
+    opt = OracleBertAdam(list(om.named_parameters()), lr=3e-5, bert_lr=3e-5, warmup=0.1, t_total=1000)
+    b2t = stc.bottom2top_matrix(labels.top2bottom)
+    oracle_step(om, opt, t, labels.top2bottom, b2t, skip_unused_transcript=True)      # warm-up
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < seconds_budget * 0.5 and n < 12):
+        oracle_step(om, opt, t, labels.top2bottom, b2t, skip_unused_transcript=True)
+        n += 1
+    dt = time.time() - t0
+    return dict(value=round(8 * n / dt, 3), unit="utterances/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d steps of bert-base fp32 B=8 S=128 n_best=5 (fwd+loss+bwd+BertAdam), oracle on CPU" % n)
+
+
+def time_dominant_kernel(M, H, F, iters=20):
+    """FFN-up forward GEMM [M,H]x[F,H]^T + bias + GELU (gemm_bf16_kernel<0,0,BIAS_GELU>): avg launch duration
+    by HIP events on the launch stream"""
+    dev = "cuda"
+    x = (torch.randn(M, H, device=dev) * 0.5).bfloat16()
+    w = (torch.randn(F, H, device=dev) * 0.03).bfloat16()
+    bias = torch.randn(F, device=dev) * 0.02
+    out = torch.empty(M, F, dtype=torch.bfloat16, device=dev)
+    U = torch.empty_like(out)
+    for _ in range(3):
+        hb.gemm(x, w, M, F, H, epilogue=hb.EPI_BIAS_GELU, bias=bias, out=out, U=U)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        hb.gemm(x, w, M, F, H, epilogue=hb.EPI_BIAS_GELU, bias=bias, out=out, U=U)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * F * H
+
+
+def note(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
+    ap.add_argument("--seq_len", type=int, default=128)
+    ap.add_argument("--n_best", type=int, default=5)
+    ap.add_argument("--model", default="bert", choices=["bert", "xlm-roberta"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--add_l2_loss", action="store_true")
+    ap.add_argument("--no_dropout", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = init_distributed()
+    assert world == a.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    labels = ncfg.LabelSpace.from_json(os.path.join(ROOT, "tests", "golden", "label_space.json"))
+    cfg = ncfg.NAMED[a.model]()
+    if a.no_dropout:
+        cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=dtype, dropout=0.0 if a.no_dropout else 0.3, seed=999)
+    model.load_reference_state(synth.model_state(cfg, labels, seed=999))     # random init of the named architecture
+    broadcast_parameters(model)
+    model.train()
+    St = a.seq_len // 4 if a.add_l2_loss else 0
+    b = synth.nbest_batch(cfg, labels, a.batch, a.seq_len, n_best=a.n_best, seed=999 + rank, trans_len=St or None)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    t_total = 100000
+    optim = HipBertAdam(model, lr=3e-5, bert_lr=3e-5, warmup=0.1, t_total=t_total)
+    reducer = GradReducer(model.arena) if world > 1 else None
+
+    def step():
+        return train_step(model, optim, batch, add_l2_loss=a.add_l2_loss, add_segment_ids=True, reducer=reducer)
+
+    if rank == 0:
+        note("model + batch resident on %s; warm-up %d steps" % (dev, a.warmup))
+    for i in range(a.warmup):
+        step()
+        if i == 0:
+            torch.cuda.synchronize()
+            if rank == 0:
+                note("first step done")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if rank == 0:
+        note("timing %d steps" % a.steps)
+    t0 = time.time()
+    for _ in range(a.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss = float(out["loss_parts"].sum().item())
+    assert np.isfinite(loss), "non-finite loss in the timed region"
+
+    if rank == 0:
+        note("timed region: %.3f s, %.1f utt/s" % (dt, a.batch * world * a.steps / dt))
+        utt = a.batch * world * a.steps / dt
+        fpu = flops_per_utt(cfg, a.seq_len, St)
+        res = {
+            "metric": "utterances/sec fine-tune (bert-base, seq128, n_best=5)" if a.model == "bert" else "utterances/sec fine-tune (%s)" % a.model,
+            "value": round(utt, 2), "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %s shape (random init), %s, synthetic n_best=%d seq_len=%d, batch %d per GPU, "
+                                   "fwd+losses+bwd+allreduce+BertAdam, dropout %s" % (
+                                       "bert-base-uncased" if a.model == "bert" else "xlm-roberta-base", a.dtype, a.n_best, a.seq_len,
+                                       a.batch, "off" if a.no_dropout else "on (0.1/0.1/0.3)"),
+                       "global_batch": a.batch * world, "seq_len": a.seq_len, "n_best": a.n_best, "parallelism": "dp%d" % world,
+                       "add_l2_loss": bool(a.add_l2_loss)},
+            "flops_per_utterance": fpu,
+            "step_mfma_frac": round(utt * fpu / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+            "last_loss_per_utt": round(loss / a.batch, 4),
+        }
+        if a.dtype == "bf16":
+            ms, fl = time_dominant_kernel(a.batch * a.seq_len, cfg.hidden_size, cfg.intermediate_size)
+            ach = fl / (ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "kernel": "gemm_bf16_kernel<false,false,BIAS_GELU> (FFN-up fwd, M=%d N=%d K=%d)" % (
+                                   a.batch * a.seq_len, cfg.intermediate_size, cfg.hidden_size),
+                               "avg_launch_ms": round(ms, 4), "flops_per_launch": fl}
+        if world == 1 and not a.no_cpu_baseline:
+            note("cpu baseline (oracle on host cores) ...")
+            res["cpu_baseline"] = cpu_baseline(labels)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -240,12 +240,16 @@ size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);
 int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wts, const float* prm, const int64_t* ids,
                           const int64_t* seg, const int64_t* pos, const uint8_t* key_mask, void* act,
                           size_t act_bytes, void* ws, size_t ws_bytes, void** hidden_out, nbest_stream_t stream);
-/* dhidden [M][H] (dtype) is consumed (overwritten).  Parameter gradients are written into `grad`
- * (overwritten; accumulate != 0: added).                                                            */
+/* dhidden [M][H] (dtype) is consumed (overwritten): it always holds the running gradient w.r.t. the
+ * input of the lowest layer processed so far.  Parameter gradients are written into `grad`
+ * (overwritten; accumulate != 0: added).  Layers [layer_begin, layer_end) are processed in reverse;
+ * with_embeddings != 0 also runs the embedding backward (needs layer_begin == 0).  Calling it in
+ * chunks (L..k, k..0+embeddings) lets the host start the gradient all-reduce of finished layers
+ * while the remaining backward runs.                                                                */
 int nbest_encoder_backward(const nbest_encoder_desc* d, const void* wts, const float* prm, float* grad,
                            const int64_t* ids, const int64_t* seg, const int64_t* pos, const uint8_t* key_mask,
                            void* act, size_t act_bytes, void* dhidden, void* ws, size_t ws_bytes, int accumulate,
-                           nbest_stream_t stream);
+                           int layer_begin, int layer_end, int with_embeddings, nbest_stream_t stream);
 
 #ifdef __cplusplus
 }

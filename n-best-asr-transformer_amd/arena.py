@@ -1,0 +1,167 @@
+"""Flat parameter arenas in HBM.
+
+All parameters of the model (encoder + STC heads, 109.6 M for bert-base) live in ONE contiguous fp32
+buffer ``p`` (the master copy); gradients ``g`` and the BertAdam moments ``m``/``v`` are buffers of the
+same layout, and the bf16 *compute copy* ``w16`` read by the MFMA GEMMs mirrors it at the same element
+offsets.  Consequences:
+
+* the HIP encoder takes two base pointers plus a per-layer offset table (no per-tensor marshalling);
+* the fused Q|K|V weight [3H,H] is simply the three HF tensors placed back to back, so HuggingFace
+  checkpoints load with no repacking and ``state_dict()`` keeps the reference's key names
+  (/root/reference/models/model.py:75-83);
+* data-parallel gradient exchange is a few large all-reduces over slices of ``g`` (layer-ordered);
+* BertAdam is one multi-tensor launch over the arenas (nbest_bertadam_step).
+
+``nn.Parameter`` objects of the module tree are *views* into ``p`` and their ``.grad`` are views into
+``g``.
+"""
+import ctypes as C
+
+import torch
+
+from . import hipabi as hb
+from .synth import encoder_param_shapes, head_param_shapes
+
+ALIGN = 64  # elements; keeps every tensor 128-byte aligned in bf16 and 256-byte aligned in fp32
+
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")   # /root/reference/n_best_asr_bert.py:540
+
+
+class Slot:
+    __slots__ = ("name", "shape", "offset", "numel")
+
+    def __init__(self, name, shape, offset):
+        self.name, self.shape, self.offset = name, tuple(shape), offset
+        n = 1
+        for s in shape:
+            n *= s
+        self.numel = n
+
+
+class ParamArena:
+    def __init__(self, cfg, labels, device, compute_dtype=torch.bfloat16):
+        self.cfg, self.labels, self.device, self.compute_dtype = cfg, labels, torch.device(device), compute_dtype
+        self.slots, self.by_name = [], {}
+        off = 0
+
+        def add(name, shape, align=True):
+            nonlocal off
+            if align:
+                off = (off + ALIGN - 1) // ALIGN * ALIGN
+            s = Slot(name, shape, off)
+            self.slots.append(s)
+            self.by_name[name] = s
+            off += s.numel
+            return s
+
+        enc = dict(encoder_param_shapes(cfg))
+        pre = "bert_encoder."
+        for n in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+                  "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"):
+            add(pre + n, enc[n])
+        self.layer_offsets = (hb.LayerOffsets * cfg.num_hidden_layers)()
+        self.layer_range = []
+        for i in range(cfg.num_hidden_layers):
+            lp = "encoder.layer.%d." % i
+            lo = None
+            o = self.layer_offsets[i]
+            for j, nm in enumerate(("query", "key", "value")):           # fused [3H,H]: contiguous, no padding
+                s = add(pre + lp + "attention.self.%s.weight" % nm, enc[lp + "attention.self.%s.weight" % nm], align=(j == 0))
+                if j == 0:
+                    o.wqkv, lo = s.offset, s.offset
+            for j, nm in enumerate(("query", "key", "value")):
+                s = add(pre + lp + "attention.self.%s.bias" % nm, enc[lp + "attention.self.%s.bias" % nm], align=(j == 0))
+                if j == 0:
+                    o.bqkv = s.offset
+            for field, nm in (("wo", "attention.output.dense.weight"), ("bo", "attention.output.dense.bias"),
+                              ("ln1_g", "attention.output.LayerNorm.weight"), ("ln1_b", "attention.output.LayerNorm.bias"),
+                              ("w1", "intermediate.dense.weight"), ("b1", "intermediate.dense.bias"),
+                              ("w2", "output.dense.weight"), ("b2", "output.dense.bias"),
+                              ("ln2_g", "output.LayerNorm.weight"), ("ln2_b", "output.LayerNorm.bias")):
+                setattr(o, field, add(pre + lp + nm, enc[lp + nm]).offset)
+            self.layer_range.append((lo, off))
+        add(pre + "pooler.dense.weight", enc["pooler.dense.weight"])
+        add(pre + "pooler.dense.bias", enc["pooler.dense.bias"])
+        heads = head_param_shapes(labels, cfg.hidden_size)
+        w_names = [n for n, _ in heads if n.endswith("weight")]
+        b_names = [n for n, _ in heads if n.endswith("bias")]
+        hs = dict(heads)
+        for j, n in enumerate(w_names):                                    # Wh [R,H] contiguous
+            s = add("clf." + n, hs[n], align=(j == 0))
+            if j == 0:
+                self.off_wh = s.offset
+        for j, n in enumerate(b_names):                                    # bh [R] contiguous
+            s = add("clf." + n, hs[n], align=(j == 0))
+            if j == 0:
+                self.off_bh = s.offset
+        self.total = (off + ALIGN - 1) // ALIGN * ALIGN
+        self.heads_range = (self.off_wh, off)
+        self.emb_range = (0, self.layer_range[0][0]) if self.layer_range else (0, self.by_name[pre + "pooler.dense.weight"].offset)
+
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.p = torch.zeros(self.total, **f32)
+        self.g = torch.zeros(self.total, **f32)
+        self.m = None
+        self.v = None
+        self.w16 = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) if compute_dtype == torch.bfloat16 else None
+        self._descs = None
+
+    # ---- views ---------------------------------------------------------------------------------
+    def view(self, buf, name):
+        s = self.by_name[name]
+        return buf[s.offset:s.offset + s.numel].view(s.shape)
+
+    def heads_wb(self):
+        R, H = self.labels.n_head_rows, self.cfg.hidden_size
+        return self.p[self.off_wh:self.off_wh + R * H].view(R, H), self.p[self.off_bh:self.off_bh + R]
+
+    def heads_grad_wb(self):
+        R, H = self.labels.n_head_rows, self.cfg.hidden_size
+        return self.g[self.off_wh:self.off_wh + R * H].view(R, H), self.g[self.off_bh:self.off_bh + R]
+
+    @property
+    def weights(self):
+        """arena the GEMMs / gathers read: bf16 compute copy, or the fp32 master in fp32 mode"""
+        return self.w16 if self.w16 is not None else self.p
+
+    def refresh_compute_copy(self):
+        if self.w16 is not None:
+            hb.cast_bf16(self.p, self.w16)
+
+    def load_state(self, sd, strict=True):
+        """copy a reference-keyed state dict (numpy arrays or tensors) into the master arena"""
+        missing = []
+        for s in self.slots:
+            if s.name in sd:
+                src = sd[s.name]
+                src = torch.as_tensor(src)
+                if tuple(src.shape) != s.shape:
+                    raise RuntimeError("shape mismatch for %s: %s vs %s" % (s.name, tuple(src.shape), s.shape))
+                self.view(self.p, s.name).copy_(src.to(torch.float32))
+            else:
+                missing.append(s.name)
+        if strict and missing:
+            raise RuntimeError("missing keys: %s" % missing[:5])
+        self.refresh_compute_copy()
+        return missing
+
+    # ---- optimizer descriptors -----------------------------------------------------------------
+    def build_descs(self, lr, bert_lr, active=None):
+        """device array of nbest_tensor_desc, one per tensor (grouping of n_best_asr_bert.py:540-550)."""
+        chunk = hb.lib().nbest_bertadam_chunk()
+        n = len(self.slots)
+        arr = (hb.TensorDesc * n)()
+        blk = 0
+        for i, s in enumerate(self.slots):
+            d = arr[i]
+            d.offset, d.numel = s.offset, s.numel
+            d.lr = bert_lr if "bert_encoder" in s.name else lr
+            d.wd = 0.0 if any(nd in s.name for nd in NO_DECAY) else 0.01
+            d.active = 0 if "pooler" in s.name else 1            # never receives a gradient
+            if active is not None:
+                d.active = int(bool(active(s.name)))
+            d.block_start = blk
+            blk += (s.numel + chunk - 1) // chunk
+        raw = bytes(arr)
+        dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        return dev, n, blk

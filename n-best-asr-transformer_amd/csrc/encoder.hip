@@ -178,8 +178,9 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
 extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* wts, const float* prm, float* grad,
                                       const int64_t* ids, const int64_t* seg, const int64_t* pos, const uint8_t* key_mask,
                                       void* act, size_t act_bytes, void* dhidden, void* ws, size_t ws_bytes, int accumulate,
-                                      nbest_stream_t stream) {
+                                      int layer_begin, int layer_end, int with_embeddings, nbest_stream_t stream) {
   RUN(check_desc(d));
+  NB_CHECK(0 <= layer_begin && layer_begin <= layer_end && layer_end <= d->L, NBEST_ERR_ARG, "encoder_backward: bad layer range");
   NB_CHECK(wts && prm && grad && ids && pos && key_mask && act && dhidden && ws, NBEST_ERR_ARG, "encoder_backward: null pointer");
   const ActLayout a = act_layout(d);
   const WsLayout w = ws_layout(d);
@@ -202,7 +203,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   void* red = W + w.red; void* slab = W + w.slab;
   const uint32_t sb = d->drop_stream_base;
 
-  for (int l = d->L - 1; l >= 0; --l) {
+  for (int l = layer_end - 1; l >= layer_begin; --l) {
     const nbest_layer_offsets& o = d->layers_host[l];
     char* Lb = A + a.layer0 + (size_t)l * a.layer_stride;
     void* qkv = Lb + a.o_qkv; void* ctx = Lb + a.o_ctx; float* lse = (float*)(Lb + a.o_lse);
@@ -236,6 +237,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
              w.slab_bytes, accumulate, 0.f, 0, 0, st));
   }
+  if (!with_embeddings) return NBEST_OK;
   if (!accumulate) {
     hipError_t e = hipMemsetAsync(G(d->off_word), 0, (size_t)d->vocab * H * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(G(d->off_pos), 0, (size_t)d->max_pos * H * sizeof(float), st);

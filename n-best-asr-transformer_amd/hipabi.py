@@ -98,7 +98,7 @@ def lib():
         L.nbest_bertadam_step.argtypes = [vp] * 6 + [i32, i32, f32, f32, f32, f32, f32, vp, sz, vp]
         L.nbest_cast_f32_to_bf16.argtypes = [vp, vp, i64, vp]
         L.nbest_encoder_forward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 7 + [sz, vp, sz, C.POINTER(C.c_void_p), vp]
-        L.nbest_encoder_backward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 8 + [sz, vp, vp, sz, i32, vp]
+        L.nbest_encoder_backward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 8 + [sz, vp, vp, sz, i32, i32, i32, i32, vp]
         L.nbest_last_error.argtypes = [C.c_char_p, sz]
         _lib = L
     return _lib

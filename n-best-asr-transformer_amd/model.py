@@ -1,0 +1,248 @@
+"""TOD_ASR_Transformer_STC-compatible model whose encoder, heads and losses run as hand-written HIP.
+
+Mirrors the reference interface of /root/reference/models/model.py:
+  * ``make_model(opt)``                                                        (:7-9)
+  * ``model(opt, input_ids, trans_input_ids, seg_ids=, trans_seg_ids=, classifier_input_type=)``
+    -> ``(top_scores, bottom_scores_dict, final_scores, asr_cls, trans_cls)``  (:35-73)
+  * ``save_model / load_model`` with the reference's state-dict keys            (:75-83)
+  * parameters named ``bert_encoder.*`` / ``clf.*`` with HF sub-names, so the learning-rate and
+    weight-decay grouping of /root/reference/n_best_asr_bert.py:540-550 applies unchanged.
+
+Training does not go through torch autograd: ``forward_backward`` enqueues the whole step
+(2 encoder passes when --add_l2_loss, heads + losses, backward) through the C-ABI and leaves the
+gradients in the flat arena ``arena.g`` (also visible as ``param.grad`` views).
+"""
+import ctypes as C
+import types
+
+import torch
+import torch.nn as nn
+
+from . import hipabi as hb
+from .arena import ParamArena
+from .config import EncoderConfig, LabelSpace, NAMED
+
+
+def position_ids_for(cfg, input_ids):
+    """BERT: arange(S).  RoBERTa family: cumsum(ids != pad) * (ids != pad) + pad (pad-offset positions)."""
+    B, S = input_ids.shape
+    if cfg.family in ("roberta", "xlm-roberta"):
+        nonpad = input_ids.ne(cfg.pad_token_id).long()
+        return (torch.cumsum(nonpad, dim=1) * nonpad + cfg.pad_token_id).contiguous()
+    return torch.arange(S, dtype=torch.long, device=input_ids.device).unsqueeze(0).expand(B, S).contiguous()
+
+
+class _Holder(nn.Module):
+    """module tree node that only carries arena-backed parameters under HF names"""
+
+
+def _attach(root, dotted, param):
+    mod = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, _Holder())
+        mod = getattr(mod, p)
+    mod.register_parameter(parts[-1], param)
+
+
+class _Pass:
+    """activation stash + descriptor of one encoder pass shape (B, S)"""
+
+    def __init__(self, model, B, S, stream_base):
+        a, cfg = model.arena, model.cfg
+        d = hb.EncoderDesc()
+        d.dtype = hb.dtype_code(model.compute_dtype)
+        d.B, d.S, d.H, d.L, d.heads, d.F = B, S, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.intermediate_size
+        d.vocab, d.max_pos, d.n_types = cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size
+        d.ln_eps = cfg.layer_norm_eps
+        d.word_pad_id = cfg.pad_token_id
+        d.pos_pad_id = cfg.pad_token_id if cfg.family in ("roberta", "xlm-roberta") else -1
+        pre = "bert_encoder.embeddings."
+        d.off_word = a.by_name[pre + "word_embeddings.weight"].offset
+        d.off_pos = a.by_name[pre + "position_embeddings.weight"].offset
+        d.off_type = a.by_name[pre + "token_type_embeddings.weight"].offset
+        d.off_emb_ln_g = a.by_name[pre + "LayerNorm.weight"].offset
+        d.off_emb_ln_b = a.by_name[pre + "LayerNorm.bias"].offset
+        d.layers_host = C.cast(a.layer_offsets, C.POINTER(hb.LayerOffsets))
+        d.drop_stream_base = stream_base
+        self.desc = d
+        L = hb.lib()
+        self.act = torch.empty(L.nbest_encoder_act_bytes(C.byref(d)), dtype=torch.uint8, device=a.device)
+        self.B, self.S = B, S
+        self.hidden = None
+        self.inputs = None
+
+
+class NBestSTCModel(nn.Module):
+    def __init__(self, cfg: EncoderConfig, labels: LabelSpace, device="cuda", compute_dtype=torch.bfloat16, dropout=0.0,
+                 seed=999):
+        super().__init__()
+        self.cfg, self.labels, self.compute_dtype = cfg, labels, compute_dtype
+        self.dropout = float(dropout)                  # --dropout: feature dropout of the STC heads
+        self.device = torch.device(device)
+        self.arena = ParamArena(cfg, labels, self.device, compute_dtype)
+        self.bert_encoder = _Holder()
+        self.clf = _Holder()
+        for s in self.arena.slots:
+            p = nn.Parameter(self.arena.view(self.arena.p, s.name), requires_grad="pooler" not in s.name)
+            if p.requires_grad:
+                p.grad = self.arena.view(self.arena.g, s.name)
+            root, rest = s.name.split(".", 1)
+            _attach(getattr(self, root), rest, p)
+        self.dls = hb.DeviceLabelSpace(labels, self.device)
+        self.seed = int(seed)
+        self.step_counter = 0
+        self._passes = {}
+        self._ws = None
+        self._ws_bytes = 0
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        self.arena.g.zero_()
+
+    def load_reference_state(self, sd, strict=True):
+        return self.arena.load_state(sd, strict)
+
+    def save_model(self, path):
+        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, path)
+
+    def load_model(self, path):
+        self.arena.load_state(torch.load(path, map_location="cpu", weights_only=True))
+
+    def _pass(self, B, S, slot):
+        key = (B, S, slot)
+        if key not in self._passes:
+            self._passes[key] = _Pass(self, B, S, stream_base=1000 * slot)
+        ps = self._passes[key]
+        need = hb.lib().nbest_encoder_ws_bytes(C.byref(ps.desc))
+        if need > self._ws_bytes:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        return ps
+
+    def _encode(self, ps, ids, seg, train):
+        """one encoder pass through the C-ABI; returns hidden states [B*S, H] (a view into the stash)"""
+        cfg = self.cfg
+        ids = ids.contiguous()
+        mask = (ids > 0).to(torch.uint8)               # quirk Q1: ids > 0 for EVERY family (models/model.py:43)
+        pos = position_ids_for(cfg, ids)
+        if cfg.family == "xlm-roberta":
+            seg = None                                  # models/model.py:42-43: XLM-R never gets token types
+        elif seg is not None:
+            seg = seg.contiguous()
+        d = ps.desc
+        d.hidden_drop = cfg.hidden_dropout_prob if train else 0.0
+        d.attn_drop = cfg.attention_probs_dropout_prob if train else 0.0
+        d.seed = self.seed + 7919 * self.step_counter
+        out = C.c_void_p()
+        hb.check(hb.lib().nbest_encoder_forward(C.byref(d), hb.ptr(self.arena.weights), hb.ptr(self.arena.p), hb.ptr(ids),
+                                                hb.ptr(seg), hb.ptr(pos), hb.ptr(mask), hb.ptr(ps.act), ps.act.numel(),
+                                                hb.ptr(self._ws), self._ws_bytes, C.byref(out), hb.stream_ptr()),
+                 "encoder_forward")
+        ps.inputs = (ids, seg, pos, mask)
+        off = out.value - ps.act.data_ptr()
+        M, H = ps.B * ps.S, cfg.hidden_size
+        esz = 2 if self.compute_dtype == torch.bfloat16 else 4
+        ps.hidden = ps.act[off:off + M * H * esz].view(self.compute_dtype).view(M, H)
+        return ps.hidden
+
+    def _backward_pass(self, ps, dcls, accumulate, chunks=None, on_chunk_done=None):
+        cfg = self.cfg
+        dh = hb.cls_grad_scatter(dcls, ps.B, ps.S, cfg.hidden_size, self.compute_dtype)
+        ids, seg, pos, mask = ps.inputs
+        L = cfg.num_hidden_layers
+        bounds = chunks or [(0, L)]
+        for (lo, hi) in sorted(bounds, reverse=True):
+            hb.check(hb.lib().nbest_encoder_backward(C.byref(ps.desc), hb.ptr(self.arena.weights), hb.ptr(self.arena.p),
+                                                     hb.ptr(self.arena.g), hb.ptr(ids), hb.ptr(seg), hb.ptr(pos), hb.ptr(mask),
+                                                     hb.ptr(ps.act), ps.act.numel(), hb.ptr(dh), hb.ptr(self._ws), self._ws_bytes,
+                                                     int(accumulate), lo, hi, int(lo == 0), hb.stream_ptr()), "encoder_backward")
+            if on_chunk_done is not None:
+                on_chunk_done(lo, hi)
+
+    def _heads(self, hidden, S, labels_f, need_grad, train, accumulate=False):
+        B, H = hidden.shape[0] // S, self.cfg.hidden_size
+        Wh, bh = self.arena.heads_wb()
+        dWh, dbh = self.arena.heads_grad_wb()
+        if labels_f is None:
+            labels_f = torch.zeros(B, self.labels.n_bottom, dtype=torch.float32, device=self.device)
+        return hb.stc_heads(hidden, S * H, Wh, bh, self.dls, labels_f.contiguous(), B, H, need_grad=need_grad,
+                            accumulate=accumulate, drop_p=self.dropout if train else 0.0,
+                            seed=self.seed + 7919 * self.step_counter, drop_stream=900, dWh=dWh, dbh=dbh)
+
+    def _bottoms_dict(self, bott):
+        out, col = {}, 0
+        for t in self.labels.multi:
+            n = len(self.labels.top2bottom[t])
+            out["lin_%d" % t] = bott[:, col:col + n]
+            col += n
+        return out
+
+    # ---- reference-compatible inference forward (models/model.py:35-73) -------------------------
+    @torch.no_grad()
+    def forward(self, opt, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, return_attns=False,
+                classifier_input_type="asr"):
+        train = self.training
+        B, S = input_ids.shape
+        pa = self._pass(B, S, 0)
+        ha = self._encode(pa, input_ids, seg_ids, train)
+        asr_cls = ha.view(B, S, -1)[:, 0, :].float()
+        trans_cls, ht, St = None, None, None
+        if trans_input_ids is not None:
+            St = trans_input_ids.shape[1]
+            pt = self._pass(B, St, 1)
+            ht = self._encode(pt, trans_input_ids, trans_seg_ids, train)
+            trans_cls = ht.view(B, St, -1)[:, 0, :].float()
+        feats, Sf = (ht, St) if classifier_input_type == "transcript" else (ha, S)
+        top, bott, fin, _, _, _, _ = self._heads(feats, Sf, None, need_grad=False, train=train)
+        return top, self._bottoms_dict(bott), fin, asr_cls, trans_cls
+
+    # ---- one training forward + backward (n_best_asr_bert.py:249-264) ---------------------------
+    def forward_backward(self, input_ids, labels_f, seg_ids=None, trans_input_ids=None, trans_seg_ids=None,
+                         add_l2_loss=False, mse_grad_scale=1.0, chunks=None, on_chunk_done=None, need_grad=True):
+        """Returns dict(top, bott, final, loss_parts[4] (device), asr_cls, trans_cls).  Gradients of the sum
+        BCE(final) + BCE(top) + mean-CE (+ MSE) are left in ``arena.g``.  The transcript pass runs only
+        when its output is used (--add_l2_loss); the reference computes and discards it otherwise (Q4)."""
+        train = self.training
+        B, S = input_ids.shape
+        H = self.cfg.hidden_size
+        pa = self._pass(B, S, 0)
+        ha = self._encode(pa, input_ids, seg_ids, train)
+        pt = ht = None
+        St = 0
+        if add_l2_loss and trans_input_ids is not None:
+            St = trans_input_ids.shape[1]
+            pt = self._pass(B, St, 1)
+            ht = self._encode(pt, trans_input_ids, trans_seg_ids, train)
+        top, bott, fin, loss, dcls, _, _ = self._heads(ha, S, labels_f, need_grad=need_grad, train=train)
+        dt = None
+        if pt is not None:
+            dt = torch.empty(B, H, dtype=torch.float32, device=self.device) if need_grad else None
+            mse = hb.cls_mse(ha, S * H, ht, St * H, B, H, dcls, dt, grad_scale=mse_grad_scale)
+            loss[3:4].copy_(mse)
+        if need_grad:
+            if pt is not None:
+                # transcript pass first (whole stack, no overlap hooks), then the ASR pass accumulates on top
+                self._backward_pass(pt, dt, accumulate=False)
+                self._backward_pass(pa, dcls, accumulate=True, chunks=chunks, on_chunk_done=on_chunk_done)
+            else:
+                self._backward_pass(pa, dcls, accumulate=False, chunks=chunks, on_chunk_done=on_chunk_done)
+        self.step_counter += 1
+        return dict(top=top, bott=bott, final=fin, loss_parts=loss, asr_cls=ha.view(B, S, H)[:, 0, :],
+                    trans_cls=None if ht is None else ht.view(B, St, H)[:, 0, :])
+
+    def decode(self, top, bott):
+        """device decode of pred_one_sample -> int32 [B, n_top] bottom-label index or -1"""
+        return hb.stc_decode(top, bott, self.dls)
+
+
+def make_model(opt):
+    """Drop-in for /root/reference/models/model.py:7-9.  ``opt`` carries the reference's fields:
+    pre_trained_model ('bert' | 'xlm-roberta' | ...), top2bottom_dict, dropout, device; optional build
+    extensions: encoder_config (EncoderConfig), compute_dtype, idx2label, random_seed."""
+    cfg = getattr(opt, "encoder_config", None) or NAMED[getattr(opt, "pre_trained_model", None) or "bert"]()
+    labels = LabelSpace(opt.top2bottom_dict, list(getattr(opt, "idx2label", []) or []))
+    return NBestSTCModel(cfg, labels, device=getattr(opt, "device", "cuda"),
+                         compute_dtype=getattr(opt, "compute_dtype", torch.bfloat16), dropout=getattr(opt, "dropout", 0.0),
+                         seed=getattr(opt, "random_seed", 999))

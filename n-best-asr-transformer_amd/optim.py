@@ -1,0 +1,58 @@
+"""BertAdam over the flat parameter arena, one multi-tensor HIP launch set per step.
+
+Interface and semantics of /root/reference/models/optimization.py:183-302 as driven by
+/root/reference/n_best_asr_bert.py:540-561: each parameter tensor is its own group (lr = bert_lr for
+``bert_encoder.*`` else lr; weight_decay 0.01 except bias / LayerNorm), gradient clipped PER TENSOR to
+L2 norm 1.0, no bias correction, eps 1e-6, ``warmup_linear`` schedule evaluated at the step count
+BEFORE the increment.
+"""
+import torch
+
+from . import hipabi as hb
+
+
+def warmup_linear(step, t_total, warmup):
+    """optimization.py:162-171 (+ :60-61: t_total < 0 disables the schedule)"""
+    if t_total < 0:
+        return 1.0
+    x = float(step) / float(t_total)
+    if x < warmup:
+        return x / warmup
+    return max((x - 1.0) / (warmup - 1.0), 0.0)
+
+
+class HipBertAdam:
+    def __init__(self, model, lr, bert_lr=None, warmup=-1, t_total=-1, b1=0.9, b2=0.999, e=1e-6, max_grad_norm=1.0):
+        self.model, self.arena = model, model.arena
+        self.lr, self.bert_lr = lr, lr if bert_lr is None else bert_lr
+        self.warmup, self.t_total = max(warmup, 0.0), t_total
+        self.b1, self.b2, self.e, self.max_grad_norm = b1, b2, e, max_grad_norm
+        self.step_count = 0
+        a = self.arena
+        if a.m is None:
+            a.m = torch.zeros_like(a.p)
+            a.v = torch.zeros_like(a.p)
+        self.descs, self.n_tensors, self.n_blocks = a.build_descs(self.lr, self.bert_lr)
+        self.ws = torch.empty((self.n_blocks + self.n_tensors + 16) * 4, dtype=torch.uint8, device=a.device)
+
+    def get_lr_mult(self):
+        return warmup_linear(self.step_count, self.t_total, self.warmup)
+
+    def zero_grad(self):
+        self.arena.g.zero_()
+
+    def step(self):
+        a = self.arena
+        hb.check(hb.lib().nbest_bertadam_step(hb.ptr(a.p), hb.ptr(a.g), hb.ptr(a.m), hb.ptr(a.v), hb.ptr(a.w16),
+                                              hb.ptr(self.descs), self.n_tensors, self.n_blocks, self.get_lr_mult(),
+                                              self.b1, self.b2, self.e, self.max_grad_norm, hb.ptr(self.ws),
+                                              self.ws.numel(), hb.stream_ptr()), "bertadam_step")
+        self.step_count += 1
+
+    def state_dict(self):
+        return dict(step=self.step_count, m=self.arena.m.cpu(), v=self.arena.v.cpu())
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.arena.m.copy_(sd["m"])
+        self.arena.v.copy_(sd["v"])
