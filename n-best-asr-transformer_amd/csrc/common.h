@@ -50,10 +50,16 @@ template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16
 // 4-element vector load/store of T as float4 (16 B for fp32, 8 B for bf16)
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
+  typedef f32x4 raw_t;
+  static __device__ __forceinline__ raw_t raw_load(const float* p) { return *(const f32x4*)p; }
+  static __device__ __forceinline__ f32x4 cvt(raw_t v) { return v; }
   static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
   static __device__ __forceinline__ void store(float* p, f32x4 v) { *(f32x4*)p = v; }
 };
 template <> struct Vec4<bf16> {
+  typedef bf16x4 raw_t;
+  static __device__ __forceinline__ raw_t raw_load(const bf16* p) { return *(const bf16x4*)p; }
+  static __device__ __forceinline__ f32x4 cvt(raw_t v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
   static __device__ __forceinline__ f32x4 load(const bf16* p) {
     bf16x4 v = *(const bf16x4*)p;
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
@@ -120,6 +126,31 @@ __device__ __forceinline__ float dgelu_f(float u) {
   const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
   return cdf + u * pdf;
+}
+
+// Fast forms for the bf16 MFMA epilogues (VALU-bound otherwise: erff costs ~40 instructions).
+// erf by Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7 - two orders below bf16 resolution; GELU and
+// GELU' share the single exp(-u^2/2).  The fp32 parity path keeps erff.
+__device__ __forceinline__ void gelu_parts_fast(float u, float& cdf, float& e) {
+  const float z = fabsf(u) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  e = __expf(-z * z);                               // exp(-u^2/2)
+  const float erf_abs = fmaf(-poly * t, e, 1.0f);   // erf(|u|/sqrt2)
+  cdf = fmaf(0.5f, copysignf(erf_abs, u), 0.5f);
+}
+__device__ __forceinline__ float gelu_fast(float u) {
+  float cdf, e;
+  gelu_parts_fast(u, cdf, e);
+  return u * cdf;
+}
+__device__ __forceinline__ float dgelu_fast(float u) {
+  float cdf, e;
+  gelu_parts_fast(u, cdf, e);
+  return fmaf(u * 0.39894228040143267794f, e, cdf);
 }
 
 // ---- counter-based dropout ---------------------------------------------------------------------

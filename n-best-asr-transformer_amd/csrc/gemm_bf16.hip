@@ -110,6 +110,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
+  // epilogue operands are independent of the K loop: fetch them now so their latency hides under it
+  // (the row-contiguous epilogue layout: iteration `it` -> row it*8 + lane/8, 8 columns at (lane&7)*8)
+  constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES);
+  constexpr bool kHasR = (EPI == NBEST_EPI_BIAS_DROP_RES || EPI == NBEST_EPI_RES);
+  constexpr bool kHasUin = (EPI == NBEST_EPI_DGELU);
+  const int64_t en8 = n0 + wn * 64 + (lane & 7) * 8;
+  const int64_t erow0 = m0 + wm * 64 + (lane >> 3);
+  f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
+  if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
+  i32x4 pre[8];
+  if (kHasR || kHasUin) {
+    const bf16* src = kHasR ? p.R : (const bf16*)p.U;
+    const int64_t lds_ = kHasR ? p.ldr : p.ldu;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int64_t m = erow0 + it * 8;
+      pre[it] = (m < p.M) ? *(const i32x4*)(src + m * lds_ + en8) : i32x4{0, 0, 0, 0};
+    }
+  }
+
   if (nk > 0) {
     stage_tile<TA>(rsA, lds, m0, kbeg, p.lda, tid);
     stage_tile<TB>(rsB, lds + kTileBytes, n0, kbeg, p.ldb, tid);
@@ -139,48 +159,69 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     }
   }
 
-  // ---- epilogue: lane holds C[m][n4 .. n4+3] ------------------------------------------------------
+  // ---- epilogue -----------------------------------------------------------------------------------
+  // The accumulators (lane = 4 consecutive columns of one row, 16 rows per instruction) are restaged
+  // through LDS into a row-contiguous layout: each lane then owns 8 consecutive columns of one row, so
+  // residual / pre-activation loads and all stores are 16-byte accesses covering whole 128-byte lines
+  // (8-byte partial-line stores made the epilogue store-issue bound).  fp32 staging: bias, GELU,
+  // dropout and residual are applied in fp32 before the single rounding to bf16.
+  // Wave-private region: [64 rows][64 cols] fp32 = 16 KiB, 256-B rows, 16-B chunk index ^= row & 15.
+  __syncthreads();  // every wave has finished reading the operand stages
+  float* ep = (float*)lds + wave * 4096;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
+    const int row = i * 16 + (lane & 15);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t n4 = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-      f32x4 v = acc[i][j];
-      if (EPI == NBEST_EPI_F32_SPLITK) {
-        if (p.splits > 1) {
-          *(f32x4*)(p.slab + ((int64_t)z * p.M + m) * p.N + n4) = v;
-        } else {
-          float* c = (float*)p.C + m * p.ldc + n4;
-          if (p.accumulate) v += *(const f32x4*)c;
-          *(f32x4*)c = v;
-        }
-        continue;
-      }
-      if (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES)
-        v += *(const f32x4*)(p.bias + n4);
-      if (EPI == NBEST_EPI_BIAS_GELU) {
-        Vec4<bf16>::store(p.U + m * p.ldu + n4, v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-      }
-      if (EPI == NBEST_EPI_BIAS_DROP_RES) {
-        if (p.drop.thr16) {
-          const uint32_t k = nb_keep4(p.drop, (uint32_t)(m * p.N + n4));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
-        }
-        v += Vec4<bf16>::load(p.R + m * p.ldr + n4);
-      }
-      if (EPI == NBEST_EPI_RES) v += Vec4<bf16>::load(p.R + m * p.ldr + n4);
-      if (EPI == NBEST_EPI_DGELU) {
-        const f32x4 u = Vec4<bf16>::load(p.U + m * p.ldu + n4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(u[e]);
-      }
-      Vec4<bf16>::store((bf16*)p.C + m * p.ldc + n4, v);
+      const int c = j * 4 + (lane >> 4);
+      *(f32x4*)(ep + row * 64 + ((c ^ (row & 15)) << 2)) = acc[i][j];
     }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int pidx = it * 64 + lane, row = pidx >> 3, c8 = pidx & 7;
+    const int64_t m = m0 + wm * 64 + row;
+    const int64_t n8 = n0 + wn * 64 + c8 * 8;
+    f32x4 v0 = *(const f32x4*)(ep + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
+    f32x4 v1 = *(const f32x4*)(ep + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+    if (m >= p.M) continue;
+    if (EPI == NBEST_EPI_F32_SPLITK) {
+      float* c = (p.splits > 1) ? p.slab + ((int64_t)z * p.M + m) * p.N + n8 : (float*)p.C + m * p.ldc + n8;
+      if (p.splits == 1 && p.accumulate) { v0 += *(const f32x4*)c; v1 += *(const f32x4*)(c + 4); }
+      *(f32x4*)c = v0;
+      *(f32x4*)(c + 4) = v1;
+      continue;
+    }
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += pb0[e]; v[4 + e] += pb1[e]; }
+    }
+    if (EPI == NBEST_EPI_BIAS_GELU) {
+      Vec8<bf16>::store(p.U + m * p.ldu + n8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+    }
+    if (EPI == NBEST_EPI_BIAS_DROP_RES) {
+      if (p.drop.thr16) {
+        const uint32_t base = (uint32_t)(m * p.N + n8);
+        const uint32_t k = nb_keep4(p.drop, base) | (nb_keep4(p.drop, base + 4) << 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
+      }
+    }
+    if (EPI == NBEST_EPI_BIAS_DROP_RES || EPI == NBEST_EPI_RES) {
+      const bf16x8 r = __builtin_bit_cast(bf16x8, pre[it]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+    }
+    if (EPI == NBEST_EPI_DGELU) {
+      const bf16x8 u = __builtin_bit_cast(bf16x8, pre[it]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= dgelu_fast((float)u[e]);
+    }
+    Vec8<bf16>::store((bf16*)p.C + m * p.ldc + n8, v);
   }
 }
 
@@ -246,7 +287,7 @@ int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st) {
   NB_CHECK(a->trans_a || a->K % BK == 0, NBEST_ERR_SHAPE, "gemm(bf16): K=%lld must be a multiple of %d", (long long)a->K, BK);
   NB_CHECK(!(a->trans_a && !a->trans_b), NBEST_ERR_ARG, "gemm(bf16): trans_a without trans_b is not built");
   NB_CHECK(!a->trans_a || a->M % BM == 0, NBEST_ERR_SHAPE, "gemm(bf16): trans_a needs M %% 128 == 0");
-  NB_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0, NBEST_ERR_ALIGN, "gemm(bf16): leading dimensions must be multiples of 8");
+  NB_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 8 == 0, NBEST_ERR_ALIGN, "gemm(bf16): leading dimensions must be multiples of 8");
   NB_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0, NBEST_ERR_ALIGN,
            "gemm(bf16): pointers must be 16-byte aligned");
   GemmP p;
@@ -267,8 +308,8 @@ int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st) {
   const int epi = a->epilogue;
   if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)
     NB_CHECK(a->bias, NBEST_ERR_ARG, "gemm: epilogue %d needs bias", epi);
-  if (epi == NBEST_EPI_BIAS_DROP_RES || epi == NBEST_EPI_RES) NB_CHECK(a->R && a->ldr % 4 == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs R", epi);
-  if (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU) NB_CHECK(a->U && a->ldu % 4 == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs U", epi);
+  if (epi == NBEST_EPI_BIAS_DROP_RES || epi == NBEST_EPI_RES) NB_CHECK(a->R && a->ldr % 8 == 0 && ((uintptr_t)a->R & 15) == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs R", epi);
+  if (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU) NB_CHECK(a->U && a->ldu % 8 == 0 && ((uintptr_t)a->U & 15) == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs U", epi);
   if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1)
     NB_CHECK(a->ws && a->ws_bytes >= (size_t)p.splits * a->M * a->N * sizeof(float), NBEST_ERR_WORKSPACE,
              "gemm: split-K workspace too small (%zu < %zu)", a->ws_bytes, (size_t)p.splits * a->M * a->N * sizeof(float));

@@ -10,9 +10,9 @@
 
 namespace {
 
-constexpr int kMaxRowredBlocks = 1024;
+constexpr int kMaxRowredBlocks = 512;
 static inline int rowred_blocks(int64_t M) {
-  int64_t b = (M + 15) / 16;
+  int64_t b = (M + 31) / 32;
   if (b < 1) b = 1;
   if (b > kMaxRowredBlocks) b = kMaxRowredBlocks;
   return (int)b;
@@ -77,16 +77,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  // software prefetch: the (packed) x / dy of the NEXT row are in flight while this row is reduced
+  typename Vec4<T>::raw_t nx[VPL], nd[VPL];
+  float nmean = 0.f, nrstd = 0.f;
+  {
+    const int64_t row = r0 + wave;
+    if (row < r1) {
+      nmean = stats[2 * row]; nrstd = stats[2 * row + 1];
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) { nx[i] = Vec4<T>::raw_load(x + row * H + 4 * c); nd[i] = Vec4<T>::raw_load(dy + row * H + 4 * c); }
+      }
+    }
+  }
   for (int64_t row = r0 + wave; row < r1; row += wpb) {
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float mean = nmean, rstd = nrstd;
+    typename Vec4<T>::raw_t cx[VPL], cd[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; }
+    const int64_t nrow = row + wpb;
+    if (nrow < r1) {
+      nmean = stats[2 * nrow]; nrstd = stats[2 * nrow + 1];
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) { nx[i] = Vec4<T>::raw_load(x + nrow * H + 4 * c); nd[i] = Vec4<T>::raw_load(dy + nrow * H + 4 * c); }
+      }
+    }
     f32x4 xh[VPL], g[VPL], d[VPL];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + 64 * i;
       if (c < nvec) {
-        xh[i] = (Vec4<T>::load(x + row * H + 4 * c) - mean) * rstd;
-        d[i] = Vec4<T>::load(dy + row * H + 4 * c);
+        xh[i] = (Vec4<T>::cvt(cx[i]) - mean) * rstd;
+        d[i] = Vec4<T>::cvt(cd[i]);
         g[i] = d[i] * gm[i];
         s1 += sum4(g[i]);
         s2 += sum4(g[i] * xh[i]);
@@ -135,22 +161,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// out_k[col] (+)= sum_blk part[k][blk][col];  grid (ceil(N/64), nout), block (64,4)
+// out_k[col] (+)= sum_blk part[k][blk][col];  grid (ceil(N/64), nout), block (64,16)
 struct RowredOut {
   float* out[3];
   int accumulate[3];
 };
 __global__ void rowred_finalize_kernel(const float* __restrict__ part, int nblk, int N, RowredOut o) {
-  __shared__ float sm[4][64];
+  __shared__ float sm[16][64];
   const int k = blockIdx.y;
   const int col = blockIdx.x * 64 + threadIdx.x;
   float s = 0.f;
   if (col < N && o.out[k] != nullptr)
-    for (int b = threadIdx.y; b < nblk; b += 4) s += part[((int64_t)k * nblk + b) * N + col];
+    for (int b = threadIdx.y; b < nblk; b += 16) s += part[((int64_t)k * nblk + b) * N + col];
   sm[threadIdx.y][threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.y == 0 && col < N && o.out[k] != nullptr) {
-    s = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += sm[r][threadIdx.x];
     o.out[k][col] = o.accumulate[k] ? o.out[k][col] + s : s;
   }
 }
@@ -407,7 +435,7 @@ static int finalize(const float* part, int nblk, int N, float* o0, int a0, float
   o.out[0] = o0; o.out[1] = o1; o.out[2] = o2;
   o.accumulate[0] = a0; o.accumulate[1] = a1; o.accumulate[2] = a2;
   const int nout = o2 ? 3 : (o1 ? 2 : 1);
-  rowred_finalize_kernel<<<dim3((N + 63) / 64, nout), dim3(64, 4), 0, st>>>(part, nblk, N, o);
+  rowred_finalize_kernel<<<dim3((N + 63) / 64, nout), dim3(64, 16), 0, st>>>(part, nblk, N, o);
   NB_LAUNCH_CHECK();
   return NBEST_OK;
 }

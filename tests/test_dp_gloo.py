@@ -1,0 +1,66 @@
+"""world_size-2 gloo test (CPU) of the data-parallel plumbing: sharding, the bucketed SUM all-reduce over
+slices of the flat gradient arena in chunk order, and the metric reduction - the same GradReducer /
+shard_bounds / _finish code that runs over RCCL on the GPUs."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, trainer
+    from nbest_amd.arena import ParamArena
+    labels = ncfg.LabelSpace.from_json(os.path.join(ROOT, "tests", "golden", "label_space.json"))
+    cfg = ncfg.bert_base(num_hidden_layers=4, vocab_size=300, hidden_size=128, num_attention_heads=2, intermediate_size=256)
+    a = ParamArena(cfg, labels, "cpu", compute_dtype=torch.float32)
+    torch.manual_seed(rank)
+    a.g.copy_(torch.randn(a.total))
+    local = a.g.clone()
+    red = trainer.GradReducer(a, n_chunks=3)
+    assert red.chunks == [(0, 1), (1, 3), (3, 4)]
+    for lo, hi in sorted(red.chunks, reverse=True):              # the order the backward produces them
+        red.layers_ready(lo, hi)
+    red.wait()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = sum(gathered)
+    covered = torch.zeros(a.total, dtype=torch.bool)
+    for lo, hi in [a.emb_range, a.heads_range] + [(a.layer_range[l][0], a.layer_range[l][1]) for l in range(4)]:
+        covered[lo:hi] = True
+    ok = torch.allclose(a.g[covered], want[covered], atol=1e-6)
+    # pooler slots are never reduced (no gradient): they must be untouched
+    pl = a.by_name["bert_encoder.pooler.dense.weight"]
+    ok = ok and torch.equal(a.g[pl.offset:pl.offset + pl.numel], local[pl.offset:pl.offset + pl.numel])
+    # parameter broadcast + metric reduction
+    a.p.fill_(float(rank + 1))
+    m = type("M", (), {"arena": a})()
+    trainer.broadcast_parameters(m)
+    ok = ok and bool((a.p == 1.0).all())
+    loss, (p, r, f), acc = trainer._finish([(torch.tensor([2.0 * (rank + 1), 0, 0, 0]), 2)], (3 + rank, 1, 2, 1 + rank, 4), "cpu")
+    ok = ok and abs(loss - 1.5) < 1e-9 and abs(acc - 100 * 3 / 8) < 1e-9 and abs(p - 100 * 7 / 9) < 1e-9
+    lo, hi = trainer.shard_bounds(7, rank, world)
+    ok = ok and (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_and_metrics_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29611
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

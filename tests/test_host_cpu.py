@@ -1,0 +1,155 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/nbest_hip.h declares,
+host-side logic (input builder, fscore, schedule, arena layout, synthetic generator), and the product
+path fails loudly instead of falling back when the HIP side is unavailable."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+import nbest_amd  # noqa: F401
+from nbest_amd import config as ncfg, fscore, hipabi, inputs, synth
+from nbest_amd.optim import warmup_linear
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "nbest_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(nbest_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    assert os.path.exists(hipabi.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(hipabi.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), "libnbest_hip.so does not export %s" % sym
+    assert sorted(hipabi.EXPORTS) == declared
+    assert lib.nbest_version() == 1
+    lib.nbest_rowred_ws_bytes.restype = ctypes.c_size_t
+    lib.nbest_rowred_ws_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    assert lib.nbest_rowred_ws_bytes(32768, 768) > 0
+    assert ctypes.sizeof(hipabi.TensorDesc) == 32 and ctypes.sizeof(hipabi.LayerOffsets) == 96
+
+
+def test_no_cpu_fallback_in_product_package():
+    """nothing under the product package may import the oracle"""
+    pkg = os.path.join(ROOT, "n-best-asr-transformer_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_product_fails_loudly_without_gpu(labels):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nbest_amd.model import NBestSTCModel
+    with pytest.raises(Exception):
+        NBestSTCModel(ncfg.bert_base(num_hidden_layers=1, vocab_size=200), labels, device="cuda")
+
+
+def test_fscore_known_answers():
+    kat = json.load(open(os.path.join(GOLDEN, "kat.json")))
+    for c in kat["update_f1"]:
+        base = (0, 0, 0) if c["pred"] else (2, 3, 4)
+        assert list(fscore.update_f1(c["pred"], c["gold"], *base)) == c["out"]
+    for c in kat["compute_f1"]:
+        assert list(fscore.compute_f1(*c["inp"])) == pytest.approx(c["out"])
+    assert fscore.update_f1(["a", "b"], ["b", "c"], 0, 0, 0) == (1, 1, 1)
+    assert fscore.compute_f1(1, 1, 1) == (50, 50, 50) and fscore.compute_f1(0, 3, 9) == (0, 0, 0)
+
+
+def test_warmup_linear_schedule():
+    assert warmup_linear(0, 100, 0.1) == 0.0
+    assert warmup_linear(5, 100, 0.1) == pytest.approx(0.5)
+    assert warmup_linear(10, 100, 0.1) == pytest.approx(1.0)
+    assert warmup_linear(55, 100, 0.1) == pytest.approx(0.5)
+    assert warmup_linear(100, 100, 0.1) == 0.0 and warmup_linear(150, 100, 0.1) == 0.0
+    assert warmup_linear(7, -1, 0.1) == 1.0
+
+
+VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "hello", "how", "may", "i", "help", "you", "?", ",", "want", "cheap",
+         "food", "chi", "##nese", "##s", "uh"]
+
+
+class _Opt:
+    pre_trained_model = "bert"
+    tod_pre_trained_model = None
+    without_system_act = False
+
+
+def test_input_builder_layout():
+    tok = inputs.WordPieceTokenizer(VOCAB)
+    raw = [["[CLS]", "[SYS]", "Hello", ",", "how", "may", "I", "help", "you?", "[USR]", "i", "want", "cheap", "chinese", "[SEP]",
+            "uh", "foods", "zzz"],
+           ["[CLS]", "[SYS]", "hello", "[USR]", "cheap", "[SEP]", "food"]]
+    ids, seg, lens = inputs.prepare_inputs_for_roberta(raw, tok, _Opt(), "cpu")
+    v = {w: i for i, w in enumerate(VOCAB)}
+    row0 = [v["[CLS]"], v["hello"], v[","], v["how"], v["may"], v["i"], v["help"], v["you"], v["?"], v["[SEP]"],
+            v["i"], v["want"], v["cheap"], v["chi"], v["##nese"], v["[SEP]"], v["uh"], v["food"], v["##s"], v["[UNK]"], v["[SEP]"]]
+    assert lens == [len(row0), 7] and ids.shape == (2, len(row0))
+    assert ids[0].tolist() == row0
+    assert ids[1].tolist() == [v["[CLS]"], v["hello"], v["[SEP]"], v["cheap"], v["[SEP]"], v["food"], v["[SEP]"]] + [0] * (len(row0) - 7)
+    assert seg[0].tolist() == [0] * 9 + [1] * 12
+    assert seg[1].tolist() == [0, 0, 1, 1, 1, 1, 1] + [0] * (len(row0) - 7)          # pads carry segment 0
+    # --without_system_act: [CLS] user.. [SEP], no segment ids
+    o = _Opt()
+    o.without_system_act = True
+    ids2, seg2, _ = inputs.prepare_inputs_for_roberta(raw[1:], tok, o, "cpu")
+    assert seg2 is None and ids2[0].tolist() == [v["[CLS]"], v["cheap"], v["[SEP]"], v["food"], v["[SEP]"]]
+    # n_best cut keeps the first hypothesis only
+    ids3, _, _ = inputs.prepare_inputs_for_roberta(raw[1:], tok, _Opt(), "cpu", n_best=1)
+    assert ids3[0].tolist() == [v["[CLS]"], v["hello"], v["[SEP]"], v["cheap"], v["[SEP]"]]
+
+
+def test_synthetic_batch_layout(labels):
+    cfg = ncfg.bert_base()
+    b = synth.nbest_batch(cfg, labels, 16, 128, n_best=5, seed=3, ragged=True, trans_len=32)
+    ids, seg, y = b["ids"], b["seg"], b["labels"]
+    assert ids.shape == (16, 128) and (ids[:, 0] == cfg.cls_token_id).all()
+    for r in range(16):
+        n = int((ids[r] != 0).sum())
+        assert (ids[r, :n] != 0).all() and (ids[r, n:] == 0).all()              # right padded
+        assert int((ids[r] == cfg.sep_token_id).sum()) == 6                      # [SEP] after sys + 5 hypotheses
+        first_sep = int(np.argmax(ids[r] == cfg.sep_token_id))
+        assert (seg[r, :first_sep] == 0).all() and (seg[r, first_sep:n] == 1).all() and (seg[r, n:] == 0).all()
+        assert ids[r, n - 1] == cfg.sep_token_id
+    assert (ids[0] != 0).all()                                                  # at least one full-length row
+    for t in labels.multi:                                                       # <= 1 active bottom per multi-value top
+        assert (y[:, labels.top2bottom[t]].sum(1) <= 1).all()
+    assert ((y.sum(1) >= 1) & (y.sum(1) <= 3)).all()
+    b2 = synth.nbest_batch(cfg, labels, 16, 128, n_best=5, seed=3, ragged=True, trans_len=32)
+    assert all(np.array_equal(b[k], b2[k]) for k in b)                           # deterministic
+
+
+def test_arena_layout(labels):
+    """layout only (no device allocation): contiguity of the fused QKV / head matrices, alignment, HF names"""
+    from nbest_amd import arena as ar
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=1000)
+    a = ar.ParamArena(cfg, labels, "cpu", compute_dtype=torch.float32)
+    H = cfg.hidden_size
+    for i in range(2):
+        p = "bert_encoder.encoder.layer.%d.attention.self." % i
+        q, k, v = (a.by_name[p + n + ".weight"] for n in ("query", "key", "value"))
+        assert k.offset == q.offset + H * H and v.offset == k.offset + H * H and q.offset % 64 == 0
+        qb, kb, vb = (a.by_name[p + n + ".bias"] for n in ("query", "key", "value"))
+        assert kb.offset == qb.offset + H and vb.offset == kb.offset + H
+        assert a.layer_offsets[i].wqkv == q.offset and a.layer_offsets[i].bqkv == qb.offset
+    Wh, bh = a.heads_wb()
+    assert Wh.shape == (171, H) and bh.shape == (171,)
+    names = [s.name for s in a.slots]
+    sd_names = ["bert_encoder." + n for n, _ in synth.encoder_param_shapes(cfg)] + ["clf." + n for n, _ in synth.head_param_shapes(labels, H)]
+    assert sorted(names) == sorted(sd_names)
+    spans = sorted((s.offset, s.offset + s.numel) for s in a.slots)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1)) and spans[-1][1] <= a.total
+    sd = synth.model_state(cfg, labels, seed=1)
+    a.w16 = None
+    a.load_state(sd)
+    np.testing.assert_array_equal(a.view(a.p, "clf.linear_layers.lin_2.weight").numpy(), sd["clf.linear_layers.lin_2.weight"])
+    np.testing.assert_array_equal(Wh[:30].numpy(), sd["clf.top_linear_layer.weight"])
+    np.testing.assert_array_equal(Wh[30:105].numpy(), sd["clf.linear_layers.lin_2.weight"])
+    lo, hi = a.layer_range[1]
+    assert lo == a.layer_offsets[1].wqkv and hi > a.layer_offsets[1].ln2_b
