@@ -99,6 +99,11 @@ typedef struct nbest_gemm_args {
   float drop_p;
   uint32_t drop_stream;
   uint64_t seed;
+  float* colsum_out;        /* optional [N]: column sums of the OUTPUT C (fp32, before rounding) = the bias
+                               gradient of the layer that produced A; fused into the epilogue (not for
+                               F32_SPLITK).  Needs ws >= nbest_gemm_ws_bytes().                            */
+  int32_t colsum_accumulate; /* colsum_out += instead of = */
+  int32_t pad_;
 } nbest_gemm_args;
 size_t nbest_gemm_ws_bytes(const nbest_gemm_args* a);
 int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream);
@@ -114,10 +119,13 @@ int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream);
 int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S,
                         int heads, int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream,
                         nbest_stream_t stream);
-/* dqkv [M][3H] receives dQ | dK | dV (overwritten, no accumulation).                                */
+/* dqkv [M][3H] receives dQ | dK | dV (overwritten, no accumulation).  dbias != NULL: dbias[3H] (+)= column
+ * sums of dqkv (the Q|K|V bias gradient), fused into the kernel; ws >= nbest_attention_bwd_ws_bytes().   */
+size_t nbest_attention_bwd_ws_bytes(int B, int S, int heads);
 int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx,
-                        const float* lse, void* dqkv, int B, int S, int heads, int d, int dtype,
-                        float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream);
+                        const float* lse, void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                        int B, int S, int heads, int d, int dtype, float drop_p, uint64_t seed,
+                        uint32_t drop_stream, nbest_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K5  LayerNorm over the hidden dimension (BertSelfOutput / BertOutput LayerNorm,

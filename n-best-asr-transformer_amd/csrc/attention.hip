@@ -284,8 +284,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
 template <int NKB>
 __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                             const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
-                                                            const float* __restrict__ lse, bf16* __restrict__ dqkv, int S,
-                                                            int heads, int H, float scale, DropCfg drop) {
+                                                            const float* __restrict__ lse, bf16* __restrict__ dqkv,
+                                                            float* __restrict__ colpart, int S, int heads, int H,
+                                                            float scale, DropCfg drop) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int Sp = NKB * 32;
   char* Qt = lds;
@@ -403,7 +404,29 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16* __restri
       dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 32, lane), dq1, 0, 0, 0);
     }
   }
-  __syncthreads();  // everyone is done reading Qt / Kt / Vt: reuse them as output images
+  __syncthreads();  // everyone is done reading Qt / Kt / Vt / dSb: reuse them as output images / scratch
+  if (colpart) {
+    // fused Q|K|V bias gradient: column sums of this (sample, head)'s dQ, dK, dV -> colpart[b][3H]
+    float* cs = (float*)dSb;   // [4 waves][3][64]
+    const f32x16* tiles[6] = {&dq0, &dq1, &dk0, &dk1, &dv0, &dv1};
+#pragma unroll
+    for (int t6 = 0; t6 < 6; ++t6) {
+      float x = 0.f;
+      if (wave < NKB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x += (*tiles[t6])[r];
+      }
+      x += __shfl_xor(x, 32, 64);
+      if (lane < 32) cs[(wave * 3 + (t6 >> 1)) * 64 + (t6 & 1) * 32 + lane] = x;
+    }
+    __syncthreads();
+    if (tid < 192) {
+      const int which = tid >> 6, dcol = tid & 63;
+      const float x = (cs[(0 * 3 + which) * 64 + dcol] + cs[(1 * 3 + which) * 64 + dcol]) +
+                      (cs[(2 * 3 + which) * 64 + dcol] + cs[(3 * 3 + which) * 64 + dcol]);
+      colpart[(int64_t)b * 3 * H + which * H + h * 64 + dcol] = x;
+    }
+  }
   if (wave < NKB) {
     const int r0 = 32 * wave;
     bf16* g = dqkv + ((int64_t)b * S + r0) * ld + h * 64;
@@ -424,11 +447,11 @@ static void launch_fwd(const bf16* qkv, const uint8_t* mask, bf16* ctx, float* l
   attn_fwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d);
 }
 template <int NKB>
-static void launch_bwd(const bf16* qkv, const uint8_t* mask, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv, int B,
-                       int S, int heads, int H, float scale, DropCfg d, hipStream_t st) {
+static void launch_bwd(const bf16* qkv, const uint8_t* mask, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv,
+                       float* colpart, int B, int S, int heads, int H, float scale, DropCfg d, hipStream_t st) {
   const size_t sm = bwd_lds_bytes(NKB);
   (void)hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  attn_bwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, S, heads, H, scale, d);
+  attn_bwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d);
 }
 
 static int check_common(const char* who, int B, int S, int heads, int d, int dtype) {
@@ -464,11 +487,21 @@ extern "C" int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, voi
   return NBEST_OK;
 }
 
+int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
+
+extern "C" size_t nbest_attention_bwd_ws_bytes(int B, int S, int heads) {
+  const size_t a = (size_t)B * 3 * heads * 64 * sizeof(float);
+  const size_t b = nbest_rowred_ws_bytes((int64_t)B * S, (int64_t)3 * heads * 64);
+  return a > b ? a : b;
+}
+
 extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
-                                   void* dqkv, int B, int S, int heads, int d, int dtype, float drop_p, uint64_t seed,
-                                   uint32_t drop_stream, nbest_stream_t stream) {
+                                   void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
+                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
   NB_CHECK(qkv && key_mask && ctx && dctx && lse && dqkv, NBEST_ERR_ARG, "attention_bwd: null pointer");
   if (int e = check_common("attention_bwd", B, S, heads, d, dtype)) return e;
+  NB_CHECK(!dbias || (ws && ws_bytes >= nbest_attention_bwd_ws_bytes(B, S, heads)), NBEST_ERR_WORKSPACE,
+           "attention_bwd: bias-gradient workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int H = heads * d;
   const float scale = 1.0f / sqrtf((float)d);
@@ -479,13 +512,17 @@ extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, con
     NB_CHECK(e == hipSuccess, NBEST_ERR_LAUNCH, "attention_bwd: memset failed: %s", hipGetErrorString(e));
     attn_bwd_f32_kernel<<<dim3(B * heads, (S + 127) / 128), 128, 0, st>>>((const float*)qkv, key_mask, (const float*)ctx,
                                                                           (const float*)dctx, lse, (float*)dqkv, S, heads, H, scale, dc);
-  } else {
-    NB_CHECK(S <= 128, NBEST_ERR_SHAPE, "attention_bwd(bf16): S=%d > 128 is not built yet", S);
-    const int nkb = (S + 31) / 32;
-#define F(N) case N: launch_bwd<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, B, S, heads, H, scale, dc, st); break;
-    switch (nkb) { F(1) F(2) F(3) F(4) }
-#undef F
+    NB_LAUNCH_CHECK();
+    if (dbias) return nbest_colsum(dqkv, dbias, (int64_t)B * S, 3 * H, 3 * H, NBEST_F32, accumulate, ws, ws_bytes, stream);
+    return NBEST_OK;
   }
+  NB_CHECK(S <= 128, NBEST_ERR_SHAPE, "attention_bwd(bf16): S=%d > 128 is not built yet", S);
+  const int nkb = (S + 31) / 32;
+  float* colpart = dbias ? (float*)ws : nullptr;
+#define F(N) case N: launch_bwd<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st); break;
+  switch (nkb) { F(1) F(2) F(3) F(4) }
+#undef F
   NB_LAUNCH_CHECK();
+  if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
   return NBEST_OK;
 }

@@ -80,6 +80,12 @@ static WsLayout ws_layout(const nbest_encoder_desc* d) {
   w.dqkv = o; o += M3H;
   const int64_t maxN = d->F > 3 * d->H ? d->F : 3 * d->H;
   w.red_bytes = al(nbest_rowred_ws_bytes(M, maxN));
+  {
+    const size_t ab = al(nbest_attention_bwd_ws_bytes(d->B, d->S, d->heads));
+    if (ab > w.red_bytes) w.red_bytes = ab;
+    const size_t gb = al((size_t)((M + 127) / 128) * 2 * d->F * sizeof(float));   // fused column sums of the dU GEMM
+    if (gb > w.red_bytes) w.red_bytes = gb;
+  }
   w.red = o; o += w.red_bytes;
   w.slab_bytes = al(max_splitk_bytes(d, M));
   w.slab = o; o += w.slab_bytes;
@@ -109,8 +115,10 @@ struct Ptrs {
 
 static int gemm(int dtype, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                 int64_t ldc, int ta, int tb, int epi, const float* bias, const void* R, int64_t ldr, void* U, int64_t ldu,
-                void* ws, size_t ws_bytes, int accumulate, float drop_p, uint64_t seed, uint32_t stream_id, hipStream_t st) {
+                void* ws, size_t ws_bytes, int accumulate, float drop_p, uint64_t seed, uint32_t stream_id, hipStream_t st,
+                float* colsum_out = nullptr) {
   nbest_gemm_args g = {};
+  g.colsum_out = colsum_out; g.colsum_accumulate = accumulate;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.R = R; g.U = U; g.ws = ws; g.ws_bytes = ws_bytes;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldu = ldu;
   g.trans_a = ta; g.trans_b = tb; g.epilogue = epi; g.dtype = dtype; g.accumulate = accumulate;
@@ -214,10 +222,11 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     RUN(nbest_layernorm_bwd(dA, r2, st2, P.P(o.ln2_g), dR, hdrop ? dRd : nullptr, G(o.ln2_g), G(o.ln2_b), G(o.b2), M, H, dt, accumulate,
                             d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream));
     // FFN-down: dgrad fused with GELU' -> dU ; wgrad
-    RUN(gemm(dt, dRd, P.W(o.w2), dBig, M, F, H, H, F, F, 0, 1, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, nullptr, 0, 0, 0.f, 0, 0, st));
+    // (the FFN-up bias gradient = column sums of dU is fused into this epilogue)
+    RUN(gemm(dt, dRd, P.W(o.w2), dBig, M, F, H, H, F, F, 0, 1, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red, w.red_bytes, accumulate,
+             0.f, 0, 0, st, G(o.b1)));
     RUN(gemm(dt, dRd, hact, G(o.w2), H, F, M, H, F, F, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
-    RUN(nbest_colsum(dBig, G(o.b1), M, F, F, dt, accumulate, red, w.red_bytes, stream));
     // FFN-up: dgrad + residual gradient ; wgrad
     RUN(gemm(dt, dBig, P.W(o.w1), dB1, M, H, F, F, H, H, 0, 1, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
@@ -230,8 +239,8 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
     // attention backward -> dqkv ; QKV bias gradient
-    RUN(nbest_attention_bwd(qkv, key_mask, ctx, dctx, lse, dqkv, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream));
-    RUN(nbest_colsum(dqkv, G(o.bqkv), M, 3 * H, 3 * H, dt, accumulate, red, w.red_bytes, stream));
+    RUN(nbest_attention_bwd(qkv, key_mask, ctx, dctx, lse, dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64, dt,
+                            d->attn_drop, d->seed, s0 + 0, stream));
     // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
     RUN(gemm(dt, dqkv, P.W(o.wqkv), dA, M, H, 3 * H, 3 * H, H, H, 0, 1, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,

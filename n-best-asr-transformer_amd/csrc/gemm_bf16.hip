@@ -25,7 +25,7 @@ constexpr int kStageBytes = 2 * kTileBytes;   // A + B
 constexpr int kLdsBytes = 2 * kStageBytes;    // 2 stages = 64 KiB
 
 struct GemmP {
-  const bf16* A; const bf16* B; void* C; const float* bias; const bf16* R; bf16* U; float* slab;
+  const bf16* A; const bf16* B; void* C; const float* bias; const bf16* R; bf16* U; float* slab; float* colpart;
   int64_t M, N, K, lda, ldb, ldc, ldr, ldu;
   int64_t k_per_split;
   int tiles_m, tiles_n, splits, accumulate;
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  float colacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int pidx = it * 64 + lane, row = pidx >> 3, c8 = pidx & 7;
@@ -222,6 +223,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
       for (int e = 0; e < 8; ++e) v[e] *= dgelu_fast((float)u[e]);
     }
     Vec8<bf16>::store((bf16*)p.C + m * p.ldc + n8, v);
+    if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) colacc[e] += v[e];
+    }
+  }
+  if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {   // fused bias gradient: per-wave column sums -> partial rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = colacc[e];
+      x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+      colacc[e] = x;
+    }
+    if ((lane >> 3) == 0) {
+      float* o = p.colpart + ((int64_t)tile_m * 2 + wm) * p.N + n0 + wn * 64 + (lane & 7) * 8;
+      *(f32x4*)o = f32x4{colacc[0], colacc[1], colacc[2], colacc[3]};
+      *(f32x4*)(o + 4) = f32x4{colacc[4], colacc[5], colacc[6], colacc[7]};
+    }
   }
 }
 
@@ -241,11 +259,16 @@ static int choose_splits(const nbest_gemm_args* a, int64_t* kps) {
   const int64_t tiles = ((a->M + BM - 1) / BM) * (a->N / BN);
   int64_t splits = 1;
   if (a->epilogue == NBEST_EPI_F32_SPLITK) {
-    splits = (768 + tiles - 1) / tiles;
-    const int64_t maxs = (a->K + 255) / 256;
-    if (splits > maxs) splits = maxs;
-    if (splits > 32) splits = 32;
-    if (splits < 1) splits = 1;
+    // the chip runs 512 workgroups at a time (2 per CU): pick the smallest split count whose grid
+    // fills whole rounds (>= 93 %), so no round runs half empty; each split keeps K >= 512
+    const int64_t maxs = (a->K / 512 < 1) ? 1 : ((a->K / 512 > 32) ? 32 : a->K / 512);
+    double best = -1.0;
+    for (int64_t s = 1; s <= maxs; ++s) {
+      const int64_t blocks = tiles * s;
+      const double eff = (double)blocks / (double)(((blocks + 511) / 512) * 512);
+      if (eff > best + 1e-9) { best = eff; splits = s; }
+      if (blocks >= 400 && eff >= 0.93) { splits = s; break; }
+    }
   }
   int64_t k = (a->K + splits - 1) / splits;
   k = (k + BK - 1) / BK * BK;
@@ -275,8 +298,10 @@ static int launch_epi(const GemmP& p, int epi, int grid, hipStream_t st) {
 
 }  // namespace
 
+int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
+
 size_t nbest_gemm_bf16_ws_bytes(const nbest_gemm_args* a) {
-  if (a->epilogue != NBEST_EPI_F32_SPLITK) return 0;
+  if (a->epilogue != NBEST_EPI_F32_SPLITK) return a->colsum_out ? (size_t)((a->M + BM - 1) / BM) * 2 * a->N * sizeof(float) : 0;
   int64_t kps;
   const int splits = choose_splits(a, &kps);
   return splits > 1 ? (size_t)splits * a->M * a->N * sizeof(float) : 0;
@@ -298,6 +323,11 @@ int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st) {
   p.splits = choose_splits(a, &p.k_per_split);
   p.accumulate = a->accumulate;
   p.slab = (float*)a->ws;
+  p.colpart = nullptr;
+  if (a->colsum_out && a->epilogue != NBEST_EPI_F32_SPLITK) {
+    NB_CHECK(a->ws && a->ws_bytes >= nbest_gemm_bf16_ws_bytes(a), NBEST_ERR_WORKSPACE, "gemm: column-sum workspace too small");
+    p.colpart = (float*)a->ws;
+  }
   const int64_t a_rows = a->trans_a ? a->K : a->M, a_cols = a->trans_a ? a->M : a->K;
   const int64_t b_rows = a->trans_b ? a->K : a->N, b_cols = a->trans_b ? a->N : a->K;
   const int64_t ab = ((a_rows - 1) * a->lda + a_cols) * 2, bb = ((b_rows - 1) * a->ldb + b_cols) * 2;
@@ -319,6 +349,7 @@ int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st) {
   else if (!a->trans_a && a->trans_b) rc = launch_epi<false, true>(p, epi, grid, st);
   else rc = launch_epi<true, true>(p, epi, grid, st);
   if (rc) return rc;
+  if (p.colpart) return nbest_internal_partial_rows_sum(p.colpart, p.tiles_m * 2, (int)a->N, a->colsum_out, a->colsum_accumulate, st);
   if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1) {
     const int64_t MN = a->M * a->N;
     int64_t g = (MN / 4 + 255) / 256;

@@ -1,0 +1,473 @@
+// K2/K4/K6 second generation: bf16 MFMA GEMM with a multi-stage LDS ring kept in flight ACROSS barriers.
+//
+// v1 (gemm_bf16.hip) has one 64-deep K tile in flight per workgroup and drains it (vmcnt(0)) at every
+// barrier: the main loop is load-latency bound (~0.8 PFLOP/s at 4096^3).  Here:
+//   * BK = 32 stages in a ring of STAGES LDS buffers; STAGES-1 stages are always in flight.  The wait
+//     that retires stage t is a COUNTED `s_waitcnt vmcnt(n*(STAGES-2))` followed by a raw `s_barrier`
+//     (never __syncthreads(), which would drain the LDS-DMA queue), then stage t+STAGES-1 is issued
+//     into the buffer every wave finished reading one iteration ago.
+//   * tile 256x128 (4 waves, wave tile 128x64 = 8x4 MFMA tiles, 32 MFMA per stage and wave) for the
+//     wide GEMMs: 85 flop per staged byte instead of 64 and 0.375 LDS fragment reads per MFMA instead
+//     of 0.5; 72 KiB LDS -> still two workgroups per CU, so one workgroup's epilogue overlaps the
+//     other's main loop.  Tile 128x128 with a 4-deep ring (64 KiB) where 256x128 would leave CUs idle
+//     (N = 768: 768 tiles on 512 slots) and for the weight gradients (split-K slab traffic grows with
+//     the tile).
+//   * LDS images (LDS-DMA is lane-linear, so the swizzle lives in the SOURCE address and the read
+//     address): k-contiguous operand [rows][32 k], 64-B rows: chunk ^= (-(row>>2))&3 (conflict-free
+//     for the 16-lane groups of ds_read_b128 even though a group mixes two k-chunks);
+//     k-strided operand [32 k][cols]: chunk ^= 2*(k&3) + 8*((k>>3)&1) for ds_read_b64_tr_b16.
+//   * epilogue as v1 (fp32 restage through wave-private LDS into a row-contiguous layout, 16-byte
+//     whole-line I/O, fast erf) but in 32-row chunks, with the residual / pre-activation rows of the
+//     next chunk prefetched while the current one is processed.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+struct GemmP2 {
+  const bf16* A; const bf16* B; void* C; const float* bias; const bf16* R; bf16* U; float* slab; float* colpart;
+  int64_t M, N, K, lda, ldb, ldc, ldr, ldu;
+  int64_t k_per_split;
+  int tiles_m, tiles_n, splits, accumulate;
+  uint32_t a_bytes, b_bytes;
+  DropCfg drop;
+};
+
+__device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// one operand tile: ROWS x 32 bf16 = ROWS*4 16-byte chunks, 256 threads -> ROWS/64 DMA instructions per thread
+template <bool TR, int ROWS>
+__device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) {
+    const int p = i * 256 + tid;
+    uint32_t voff;
+    if (!TR) {
+      const int row = p >> 2, slot = p & 3;
+      const int kc = slot ^ ((-(row >> 2)) & 3);
+      voff = (uint32_t)(((row0 + row) * ld + k0 + kc * 8) * 2);
+    } else {
+      constexpr int CPR = ROWS / 8;  // 16-byte chunks per k-row
+      const int krow = p / CPR, slot = p % CPR;
+      const int mc = slot ^ (2 * (krow & 3) + 8 * ((krow >> 3) & 1));
+      voff = (uint32_t)(((k0 + krow) * ld + row0 + mc * 8) * 2);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * 256 + wave * 64) * 16), 16, voff, 0, 0, 0);
+  }
+}
+
+// 16 rows x 32 k fragment of v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8*(l>>4) + j
+template <bool TR, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag2(const char* tile, int row_base, int lane) {
+  if (!TR) {
+    const int row = row_base + (lane & 15);
+    const int kc = lane >> 4;
+    return *(const bf16x8*)(tile + row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4));
+  } else {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+    const int col = row_base + 4 * pq;
+    bf16x8 out;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int krow = 8 * g + 4 * half + q;
+      const int f = 2 * (krow & 3) + 8 * ((krow >> 3) & 1);
+      const char* addr = tile + krow * (ROWS * 2) + (((col >> 3) ^ f) << 4) + ((col & 4) ? 8 : 0);
+      const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)addr);
+      out[4 * half + 0] = v[0]; out[4 * half + 1] = v[1]; out[4 * half + 2] = v[2]; out[4 * half + 3] = v[3];
+    }
+    return out;
+  }
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else static_assert(N < 0, "add the literal");
+}
+
+template <int BM, int BN, int STAGES, bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr bool PIPE = (BM == 128);   // second fragment register set: fits only the 64x64 wave tile
+  constexpr int WTM = BM / 2, WTN = BN / 2;          // 2 x 2 waves
+  constexpr int TMt = WTM / 16, TNt = WTN / 16;
+  static_assert(WTN == 64, "row-contiguous epilogue assumes 64-column wave tiles");
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int NDMA = BM / 64 + BN / 64;            // LDS-DMA instructions per thread and stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  const int id = xcd_remap2(blockIdx.x, nwg);
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = id / tiles, t = id - z * tiles;
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+  const int64_t kbeg = (int64_t)z * p.k_per_split;
+  const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+
+  // epilogue operands that do not depend on the K loop
+  constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES);
+  constexpr bool kHasR = (EPI == NBEST_EPI_BIAS_DROP_RES || EPI == NBEST_EPI_RES);
+  constexpr bool kHasUin = (EPI == NBEST_EPI_DGELU);
+  constexpr bool kPre = kHasR || kHasUin;
+  const int64_t en8 = n0 + wn * WTN + (lane & 7) * 8;
+  const int64_t erow0 = m0 + wm * WTM + (lane >> 3);
+  const bf16* esrc = kHasR ? p.R : (const bf16*)p.U;
+  const int64_t eld = kHasR ? p.ldr : p.ldu;
+  f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
+  if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
+  i32x4 pre[2][4];
+  if (kPre) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t m = erow0 + it * 8;
+      pre[0][it] = (m < p.M) ? *(const i32x4*)(esrc + m * eld + en8) : i32x4{0, 0, 0, 0};
+    }
+  }
+
+  f32x4 acc[TMt][TNt];
+#pragma unroll
+  for (int i = 0; i < TMt; ++i)
+#pragma unroll
+    for (int j = 0; j < TNt; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  if constexpr (PIPE) {
+  // ---- ring: buffers hold stages kt+1 .. kt+STAGES; fragments of stage kt+1 are read (into the other
+  // register set) while the MFMAs of stage kt run, so no LDS round trip is exposed at a stage boundary.
+#pragma unroll
+  for (int s = 0; s < STAGES; ++s) {
+    if (s < nk) {
+      stage_tile2<TA, BM>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
+      stage_tile2<TB, BN>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+    }
+  }
+  bf16x8 afA[TMt], bfA[TNt], afB[TMt], bfB[TNt];
+  {
+    const int inflight = (nk < STAGES ? nk : STAGES) - 1;   // stages that may stay in flight behind stage 0
+    if (inflight >= 3) wait_vm<3 * NDMA>();
+    else if (inflight == 2) wait_vm<2 * NDMA>();
+    else if (inflight == 1) wait_vm<NDMA>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (nk > 0) {
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) bfA[j] = read_frag2<TB, BN>(lds + A_BYTES, wn * WTN + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < TMt; ++i) afA[i] = read_frag2<TA, BM>(lds, wm * WTM + i * 16, lane);
+    }
+  }
+  int buf = 0;  // buffer of stage kt
+  // one pipeline step: top-of-iteration sync for stage kt+1, refill the buffer stage kt occupied,
+  // read fragments of stage kt+1 into (an, bn) while multiplying (ac, bc)
+#define NB_STEP(ac, bc, an, bn)                                                                              \
+  {                                                                                                          \
+    const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1; /* stages kt+1.. still outstanding */ \
+    if (c >= 3) wait_vm<2 * NDMA>();                                                                         \
+    else if (c == 2) wait_vm<NDMA>();                                                                        \
+    else if (c == 1) wait_vm<0>();                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("" ::: "memory");                                                                           \
+    if (kt + STAGES < nk) {                                                                                  \
+      const int64_t k0 = kbeg + (int64_t)(kt + STAGES) * BK;                                                 \
+      stage_tile2<TA, BM>(rsA, lds + buf * STAGE, m0, k0, p.lda, tid);                                       \
+      stage_tile2<TB, BN>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, p.ldb, tid);                             \
+    }                                                                                                        \
+    const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;                                                      \
+    if (kt + 1 < nk) {                                                                                       \
+      const char* nx = lds + nbuf * STAGE;                                                                   \
+      _Pragma("unroll") for (int j = 0; j < TNt; ++j) bn[j] = read_frag2<TB, BN>(nx + A_BYTES, wn * WTN + j * 16, lane); \
+      _Pragma("unroll") for (int i = 0; i < TMt; ++i) an[i] = read_frag2<TA, BM>(nx, wm * WTM + i * 16, lane); \
+    }                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < TMt; ++i)                                                          \
+      _Pragma("unroll") for (int j = 0; j < TNt; ++j)                                                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[j], ac[i], acc[i][j], 0, 0, 0);               \
+    buf = nbuf;                                                                                              \
+    ++kt;                                                                                                    \
+  }
+  for (int kt = 0; kt < nk;) {
+    NB_STEP(afA, bfA, afB, bfB)
+    if (kt >= nk) break;
+    NB_STEP(afB, bfB, afA, bfA)
+  }
+#undef NB_STEP
+
+  } else {
+  // ---- plain ring (256x128: no registers left for a second fragment set): STAGES-1 stages in flight ----
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) {
+    if (s < nk) {
+      stage_tile2<TA, BM>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
+      stage_tile2<TB, BN>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+    }
+  }
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // retire stage kt: at most min(STAGES-2, nk-1-kt) younger stages may stay in flight
+    const int younger = (nk - 1 - kt < STAGES - 2) ? nk - 1 - kt : STAGES - 2;
+    if (STAGES >= 4 && younger == 2) wait_vm<2 * NDMA>();
+    else if (younger >= 1) wait_vm<NDMA>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();   // stage kt landed for all waves; all waves finished reading stage kt-1
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < nk) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
+      stage_tile2<TA, BM>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+      stage_tile2<TB, BN>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+    }
+    const char* cur = lds + buf * STAGE;
+    bf16x8 af[TMt], bfr[TNt];
+#pragma unroll
+    for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<TB, BN>(cur + A_BYTES, wn * WTN + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < TMt; ++i) af[i] = read_frag2<TA, BM>(cur, wm * WTM + i * 16, lane);
+#pragma unroll
+    for (int i = 0; i < TMt; ++i)
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+  }
+  }
+
+  // ---- epilogue: 32-row chunks restaged through wave-private LDS ([32][64] fp32, chunk16 ^= row & 15) ----
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float* ep = (float*)lds + wave * 2048;
+  float colacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < TMt / 2; ++c) {
+    if (kPre && c + 1 < TMt / 2) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t m = erow0 + (c + 1) * 32 + it * 8;
+        pre[(c + 1) & 1][it] = (m < p.M) ? *(const i32x4*)(esrc + m * eld + en8) : i32x4{0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int row = ii * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) {
+        const int cidx = j * 4 + (lane >> 4);
+        *(f32x4*)(ep + row * 64 + ((cidx ^ (row & 15)) << 2)) = acc[2 * c + ii][j];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pidx = it * 64 + lane, row = pidx >> 3, c8 = pidx & 7;
+      const int64_t m = m0 + wm * WTM + c * 32 + row;
+      const int64_t n8 = en8;
+      f32x4 v0 = *(const f32x4*)(ep + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
+      f32x4 v1 = *(const f32x4*)(ep + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+      if (m >= p.M) continue;
+      if (EPI == NBEST_EPI_F32_SPLITK) {
+        float* cp = (p.splits > 1) ? p.slab + ((int64_t)z * p.M + m) * p.N + n8 : (float*)p.C + m * p.ldc + n8;
+        if (p.splits == 1 && p.accumulate) { v0 += *(const f32x4*)cp; v1 += *(const f32x4*)(cp + 4); }
+        *(f32x4*)cp = v0;
+        *(f32x4*)(cp + 4) = v1;
+        continue;
+      }
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (kHasBias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += pb0[e]; v[4 + e] += pb1[e]; }
+      }
+      if (EPI == NBEST_EPI_BIAS_GELU) {
+        Vec8<bf16>::store(p.U + m * p.ldu + n8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+      }
+      if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
+        const uint32_t base = (uint32_t)(m * p.N + n8);
+        const uint32_t k = nb_keep4(p.drop, base) | (nb_keep4(p.drop, base + 4) << 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
+      }
+      if (kHasR) {
+        const bf16x8 r = __builtin_bit_cast(bf16x8, pre[c & 1][it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+      }
+      if (kHasUin) {
+        const bf16x8 u = __builtin_bit_cast(bf16x8, pre[c & 1][it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dgelu_fast((float)u[e]);
+      }
+      Vec8<bf16>::store((bf16*)p.C + m * p.ldc + n8, v);
+      if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colacc[e] += v[e];
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+  if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {   // fused bias gradient: per-wave column sums -> partial rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = colacc[e];
+      x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+      colacc[e] = x;
+    }
+    if ((lane >> 3) == 0) {
+      float* o = p.colpart + ((int64_t)tile_m * 2 + wm) * p.N + en8;
+      *(f32x4*)o = f32x4{colacc[0], colacc[1], colacc[2], colacc[3]};
+      *(f32x4*)(o + 4) = f32x4{colacc[4], colacc[5], colacc[6], colacc[7]};
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float* __restrict__ slab, float* __restrict__ C, int64_t MN,
+                                                             int64_t N, int64_t ldc, int splits, int accumulate) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    f32x4 s = *(const f32x4*)(slab + i);
+    for (int z = 1; z < splits; ++z) s += *(const f32x4*)(slab + (int64_t)z * MN + i);
+    const int64_t m = i / N, n = i - m * N;
+    float* c = C + m * ldc + n;
+    if (accumulate) s += *(const f32x4*)c;
+    *(f32x4*)c = s;
+  }
+}
+
+struct Plan {
+  int bm, bn, splits;
+  int64_t kps;
+};
+
+static Plan make_plan(const nbest_gemm_args* a) {
+  Plan pl;
+  pl.bn = 128;
+  // 256x128 where it fills the chip (two workgroups per CU -> 512 slots) and is not a weight gradient
+  const int64_t t256 = ((a->M + 255) / 256) * (a->N / 128);
+  pl.bm = (!a->trans_a && t256 >= 1024) ? 256 : 128;
+  const int64_t tiles = ((a->M + pl.bm - 1) / pl.bm) * (a->N / pl.bn);
+  int64_t splits = 1;
+  if (a->epilogue == NBEST_EPI_F32_SPLITK) {
+    splits = (1024 + tiles - 1) / tiles;
+    const int64_t maxs = (a->K + 511) / 512;
+    if (splits > maxs) splits = maxs;
+    if (splits > 32) splits = 32;
+    if (splits < 1) splits = 1;
+  }
+  int64_t k = (a->K + splits - 1) / splits;
+  k = (k + 63) / 64 * 64;
+  pl.splits = (int)((a->K + k - 1) / k);
+  pl.kps = k;
+  return pl;
+}
+
+template <int BM, int BN, int STAGES, bool TA, bool TB>
+static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
+  constexpr int lds_bytes = STAGES * (BM + BN) * BK * 2;
+#define L(E)                                                                                                        \
+  case E:                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, STAGES, TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    gemm2_kernel<BM, BN, STAGES, TA, TB, E><<<grid, 256, lds_bytes, st>>>(p);                                        \
+    break;
+  switch (epi) {
+    L(NBEST_EPI_NONE) L(NBEST_EPI_BIAS) L(NBEST_EPI_BIAS_GELU) L(NBEST_EPI_BIAS_DROP_RES) L(NBEST_EPI_DGELU)
+    L(NBEST_EPI_RES) L(NBEST_EPI_F32_SPLITK)
+    default:
+      nbest_set_error("gemm: bad epilogue %d", epi);
+      return NBEST_ERR_ARG;
+  }
+#undef L
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+}  // namespace
+
+// v2 is only faster with its 256x128 tile (measured: +8..14 % on the wide-N forward / dgrad GEMMs); the
+// 128x128 BK=32 ring loses to v1's 128x128 BK=64 (half the MFMAs per barrier and per DMA instruction)
+bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a) { return make_plan(a).bm == 256; }
+
+int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
+
+size_t nbest_gemm_bf16_v2_ws_bytes(const nbest_gemm_args* a) {
+  if (a->epilogue != NBEST_EPI_F32_SPLITK) {
+    if (!a->colsum_out) return 0;
+    const Plan pl0 = make_plan(a);
+    return (size_t)((a->M + pl0.bm - 1) / pl0.bm) * 2 * a->N * sizeof(float);
+  }
+  const Plan pl = make_plan(a);
+  return pl.splits > 1 ? (size_t)pl.splits * a->M * a->N * sizeof(float) : 0;
+}
+
+int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
+  NB_CHECK(a->N % 128 == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld must be a multiple of 128", (long long)a->N);
+  NB_CHECK(a->trans_a || a->K % BK == 0, NBEST_ERR_SHAPE, "gemm(bf16): K=%lld must be a multiple of %d", (long long)a->K, BK);
+  NB_CHECK(!(a->trans_a && !a->trans_b), NBEST_ERR_ARG, "gemm(bf16): trans_a without trans_b is not built");
+  NB_CHECK(!a->trans_a || a->M % 128 == 0, NBEST_ERR_SHAPE, "gemm(bf16): trans_a needs M %% 128 == 0");
+  NB_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 8 == 0, NBEST_ERR_ALIGN, "gemm(bf16): leading dimensions must be multiples of 8");
+  NB_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0, NBEST_ERR_ALIGN,
+           "gemm(bf16): pointers must be 16-byte aligned");
+  const Plan pl = make_plan(a);
+  GemmP2 p;
+  p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C; p.bias = a->bias; p.R = (const bf16*)a->R; p.U = (bf16*)a->U;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldu = a->ldu;
+  p.tiles_m = (int)((a->M + pl.bm - 1) / pl.bm);
+  p.tiles_n = (int)(a->N / pl.bn);
+  p.splits = pl.splits;
+  p.k_per_split = pl.kps;
+  p.accumulate = a->accumulate;
+  p.slab = (float*)a->ws;
+  p.colpart = nullptr;
+  if (a->colsum_out && a->epilogue != NBEST_EPI_F32_SPLITK) {
+    NB_CHECK(a->ws && a->ws_bytes >= nbest_gemm_bf16_v2_ws_bytes(a), NBEST_ERR_WORKSPACE, "gemm: column-sum workspace too small");
+    p.colpart = (float*)a->ws;
+  }
+  const int64_t a_rows = a->trans_a ? a->K : a->M, a_cols = a->trans_a ? a->M : a->K;
+  const int64_t b_rows = a->trans_b ? a->K : a->N, b_cols = a->trans_b ? a->N : a->K;
+  const int64_t ab = ((a_rows - 1) * a->lda + a_cols) * 2, bb = ((b_rows - 1) * a->ldb + b_cols) * 2;
+  NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm(bf16): operand larger than 4 GiB");
+  p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
+  NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm(bf16): dropout counter overflow");
+  const int epi = a->epilogue;
+  if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)
+    NB_CHECK(a->bias, NBEST_ERR_ARG, "gemm: epilogue %d needs bias", epi);
+  if (epi == NBEST_EPI_BIAS_DROP_RES || epi == NBEST_EPI_RES)
+    NB_CHECK(a->R && a->ldr % 8 == 0 && ((uintptr_t)a->R & 15) == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs R", epi);
+  if (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU)
+    NB_CHECK(a->U && a->ldu % 8 == 0 && ((uintptr_t)a->U & 15) == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs U", epi);
+  if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1)
+    NB_CHECK(a->ws && a->ws_bytes >= (size_t)p.splits * a->M * a->N * sizeof(float), NBEST_ERR_WORKSPACE,
+             "gemm: split-K workspace too small (%zu < %zu)", a->ws_bytes, (size_t)p.splits * a->M * a->N * sizeof(float));
+  const int grid = p.tiles_m * p.tiles_n * p.splits;
+  int rc;
+  if (pl.bm == 256) {
+    if (!a->trans_b) rc = launch2<256, 128, 3, false, false>(p, epi, grid, st);
+    else rc = launch2<256, 128, 3, false, true>(p, epi, grid, st);
+  } else {
+    if (!a->trans_a && !a->trans_b) rc = launch2<128, 128, 4, false, false>(p, epi, grid, st);
+    else if (!a->trans_a && a->trans_b) rc = launch2<128, 128, 4, false, true>(p, epi, grid, st);
+    else rc = launch2<128, 128, 4, true, true>(p, epi, grid, st);
+  }
+  if (rc) return rc;
+  if (p.colpart) return nbest_internal_partial_rows_sum(p.colpart, p.tiles_m * 2, (int)a->N, a->colsum_out, a->colsum_accumulate, st);
+  if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1) {
+    const int64_t MN = a->M * a->N;
+    int64_t g = (MN / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    splitk_reduce2_kernel<<<(int)g, 256, 0, st>>>(p.slab, (float*)a->C, MN, a->N, a->ldc, p.splits, a->accumulate);
+    NB_LAUNCH_CHECK();
+  }
+  return NBEST_OK;
+}

@@ -3,6 +3,7 @@
 // bf16 MFMA kernel.  It exists so the hand-written backward formulas and the host orchestration can
 // be checked against the oracle at 1e-4 without bf16 rounding in the way; it is not a fast path.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -121,18 +122,42 @@ int nbest_gemm_f32(const nbest_gemm_args* a, hipStream_t st) {
 // ---- public dispatcher ----------------------------------------------------------------------------
 size_t nbest_gemm_bf16_ws_bytes(const nbest_gemm_args* a);
 int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st);
+size_t nbest_gemm_bf16_v2_ws_bytes(const nbest_gemm_args* a);
+int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st);
+bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a);
+
+// NBEST_GEMM=v1 / v2 forces one generation (A/B measurements); default: per-shape choice
+static int forced_gen() {
+  static const int v = [] { const char* e = getenv("NBEST_GEMM"); return (e && e[0] == 'v' && (e[1] == '1' || e[1] == '2')) ? e[1] - '0' : 0; }();
+  return v;
+}
+static bool use_v2(const nbest_gemm_args* a) {
+  const int f = forced_gen();
+  return f == 2 || (f == 0 && nbest_gemm_bf16_v2_wins(a));
+}
 
 extern "C" size_t nbest_gemm_ws_bytes(const nbest_gemm_args* a) {
-  if (!a || a->dtype != NBEST_BF16) return 0;
-  return nbest_gemm_bf16_ws_bytes(a);
+  if (!a) return 0;
+  if (a->dtype == NBEST_F32) return (a->colsum_out && a->epilogue != NBEST_EPI_F32_SPLITK) ? nbest_rowred_ws_bytes(a->M, a->N) : 0;
+  if (a->dtype != NBEST_BF16) return 0;
+  // callers size one workspace for whichever generation runs: take the larger requirement
+  const size_t w1 = nbest_gemm_bf16_ws_bytes(a), w2 = nbest_gemm_bf16_v2_ws_bytes(a);
+  return w1 > w2 ? w1 : w2;
 }
 
 extern "C" int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream) {
   NB_CHECK(a && a->A && a->B && a->C, NBEST_ERR_ARG, "gemm: null pointer");
   NB_CHECK(a->M > 0 && a->N > 0 && a->K > 0, NBEST_ERR_SHAPE, "gemm: bad shape %lld x %lld x %lld", (long long)a->M,
            (long long)a->N, (long long)a->K);
-  if (a->dtype == NBEST_F32) return nbest_gemm_f32(a, (hipStream_t)stream);
-  if (a->dtype == NBEST_BF16) return nbest_gemm_bf16(a, (hipStream_t)stream);
+  if (a->dtype == NBEST_F32) {
+    if (int rc = nbest_gemm_f32(a, (hipStream_t)stream)) return rc;
+    if (a->colsum_out && a->epilogue != NBEST_EPI_F32_SPLITK) {
+      NB_CHECK(a->ws && a->ws_bytes >= nbest_rowred_ws_bytes(a->M, a->N), NBEST_ERR_WORKSPACE, "gemm(f32): column-sum workspace too small");
+      return nbest_colsum(a->C, a->colsum_out, a->M, a->N, a->ldc, NBEST_F32, a->colsum_accumulate, a->ws, a->ws_bytes, stream);
+    }
+    return NBEST_OK;
+  }
+  if (a->dtype == NBEST_BF16) return use_v2(a) ? nbest_gemm_bf16_v2(a, (hipStream_t)stream) : nbest_gemm_bf16(a, (hipStream_t)stream);
   nbest_set_error("gemm: bad dtype %d", a->dtype);
   return NBEST_ERR_DTYPE;
 }

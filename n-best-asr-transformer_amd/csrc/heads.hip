@@ -24,7 +24,9 @@ __device__ __forceinline__ int layer_of_row(int r, const int32_t* __restrict__ h
   return lay;
 }
 
-// logits[b][r] = sum_h Wh[r][h] * drop_{layer(r)}(cls[b][h]) + bh[r];  grid B, block 256
+// logits[b][r] = sum_h Wh[r][h] * drop_{layer(r)}(cls[b][h]) + bh[r];  grid (B, kLogitSplit), block 256:
+// blockIdx.y owns a contiguous slice of the head rows (more, shorter blocks: the kernel is latency bound)
+constexpr int kLogitSplit = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void heads_logits_kernel(const T* __restrict__ hidden, int64_t cls_stride,
                                                            const float* __restrict__ Wh, const float* __restrict__ bh,
@@ -37,18 +39,20 @@ __global__ __launch_bounds__(256) void heads_logits_kernel(const T* __restrict__
   for (int h = threadIdx.x; h < H; h += blockDim.x) {
     const float v = to_f<T>(x[h]);
     xs[h] = v;
-    cls_out[(int64_t)b * H + h] = v;
+    if (blockIdx.y == 0) cls_out[(int64_t)b * H + h] = v;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int r = wave; r < R; r += nw) {
+  const int per = (R + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = (r0 + per < R) ? r0 + per : R;
+  for (int r = r0 + wave; r < r1; r += nw) {
     const int lay = layer_of_row(r, head_row, n_top, nullptr);
     const float* w = Wh + (int64_t)r * H;
     float s = 0.f;
     for (int h = lane; h < H; h += 64) {
       float xv = xs[h];
       if (drop.thr16) xv = nb_keep(drop, (uint32_t)((lay * gridDim.x + b) * H + h)) ? xv * drop.scale : 0.f;
-      s += w[h] * xv;
+      s = fmaf(w[h], xv, s);
     }
     s = wave_sum(s);
     if (lane == 0) logits[(int64_t)b * R + r] = s + bh[r];
@@ -164,27 +168,50 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
   }
 }
 
-// dWh[r][h] = sum_b dz[b][r] * drop(cls[b][h]); dbh[r] = sum_b dz[b][r].  grid R, block 256
+// dWh[r][h] = sum_b dz[b][r] * drop(cls[b][h]); dbh[r] = sum_b dz[b][r].  grid R, block 256: the four
+// waves split the batch (b = wave, wave+4, ..), a lane owns columns lane, lane+64, ..; fixed-order LDS reduce
 __global__ __launch_bounds__(256) void heads_wgrad_kernel(const float* __restrict__ cls, const float* __restrict__ dz,
                                                           const int32_t* __restrict__ head_row, int n_top, int B, int R, int H,
                                                           float* __restrict__ dWh, float* __restrict__ dbh, int accumulate,
                                                           DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][H] + [4]
   const int r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lay = layer_of_row(r, head_row, n_top, nullptr);
-  for (int h = threadIdx.x; h < H; h += blockDim.x) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-      float xv = cls[(int64_t)b * H + h];
-      if (drop.thr16) xv = nb_keep(drop, (uint32_t)((lay * B + b) * H + h)) ? xv * drop.scale : 0.f;
-      s += dz[(int64_t)b * R + r] * xv;
+  constexpr int MAXC = 32;  // H <= 2048
+  float acc[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) acc[i] = 0.f;
+  float sb = 0.f;
+  const int nc = (H + 63) / 64;
+  for (int b = wave; b < B; b += 4) {
+    const float g = dz[(int64_t)b * R + r];
+    sb += g;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int h = lane + 64 * i;
+      if (i < nc && h < H) {
+        float xv = cls[(int64_t)b * H + h];
+        if (drop.thr16) xv = nb_keep(drop, (uint32_t)((lay * B + b) * H + h)) ? xv * drop.scale : 0.f;
+        acc[i] = fmaf(g, xv, acc[i]);
+      }
     }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int h = lane + 64 * i;
+    if (i < nc && h < H) red[wave * H + h] = acc[i];
+  }
+  if (lane == 0) red[4 * H + wave] = sb;
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += blockDim.x) {
+    const float v = (red[h] + red[H + h]) + (red[2 * H + h] + red[3 * H + h]);
     float* o = dWh + (int64_t)r * H + h;
-    *o = accumulate ? *o + s : s;
+    *o = accumulate ? *o + v : v;
   }
   if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dz[(int64_t)b * R + r];
-    dbh[r] = accumulate ? dbh[r] + s : s;
+    const float v = (red[4 * H] + red[4 * H + 1]) + (red[4 * H + 2] + red[4 * H + 3]);
+    dbh[r] = accumulate ? dbh[r] + v : v;
   }
 }
 
@@ -267,7 +294,7 @@ extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const flo
            NBEST_ERR_ARG, "stc_heads: null pointer");
   NB_CHECK(!need_grad || (dcls && dWh && dbh), NBEST_ERR_ARG, "stc_heads: need_grad without gradient buffers");
   const int R = ls->n_rows, n_top = ls->n_top, n_bottom = ls->n_bottom;
-  NB_CHECK(R > n_top && n_top > 0 && n_bottom > 0 && R <= 4096, NBEST_ERR_SHAPE, "stc_heads: bad label space");
+  NB_CHECK(R > n_top && n_top > 0 && n_bottom > 0 && R <= 4096 && H <= 2048, NBEST_ERR_SHAPE, "stc_heads: bad label space");
   NB_CHECK(ws_bytes >= nbest_heads_ws_bytes(B, R, H), NBEST_ERR_WORKSPACE, "stc_heads: workspace too small");
   NB_CHECK((int64_t)11 * B * H < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "stc_heads: B*H too large");
   hipStream_t st = (hipStream_t)stream;
@@ -284,9 +311,9 @@ extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const flo
   NB_CHECK(n_heads > 0, NBEST_ERR_SHAPE, "stc_heads: label space has no multi-value head");
   const size_t smemH = (size_t)H * sizeof(float);
   if (dtype == NBEST_F32)
-    heads_logits_kernel<float><<<B, 256, smemH, st>>>((const float*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, d);
+    heads_logits_kernel<float><<<dim3(B, kLogitSplit), 256, smemH, st>>>((const float*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, d);
   else if (dtype == NBEST_BF16)
-    heads_logits_kernel<bf16><<<B, 256, smemH, st>>>((const bf16*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, d);
+    heads_logits_kernel<bf16><<<dim3(B, kLogitSplit), 256, smemH, st>>>((const bf16*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, d);
   else NB_CHECK(false, NBEST_ERR_DTYPE, "stc_heads: bad dtype %d", dtype);
   NB_LAUNCH_CHECK();
   heads_scores_kernel<<<B, 64, 0, st>>>(logits, labels, ls->bottom_off, ls->bottom_ids, ls->head_row, n_top, n_bottom, R,
@@ -295,7 +322,7 @@ extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const flo
   loss_reduce_kernel<<<1, 256, 0, st>>>(sloss, B, loss_parts);
   NB_LAUNCH_CHECK();
   if (need_grad) {
-    heads_wgrad_kernel<<<R, 256, 0, st>>>(cls, dz, ls->head_row, n_top, B, R, H, dWh, dbh, accumulate, d);
+    heads_wgrad_kernel<<<R, 256, ((size_t)4 * H + 4) * sizeof(float), st>>>(cls, dz, ls->head_row, n_top, B, R, H, dWh, dbh, accumulate, d);
     NB_LAUNCH_CHECK();
     heads_dgrad_kernel<<<B, 256, (size_t)2 * R * sizeof(float), st>>>(Wh, dz, ls->head_row, n_top, R, H, dcls, d);
     NB_LAUNCH_CHECK();

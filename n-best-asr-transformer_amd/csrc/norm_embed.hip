@@ -442,6 +442,11 @@ static int finalize(const float* part, int nblk, int N, float* o0, int a0, float
 
 }  // namespace
 
+// out[n] (+)= sum over `nrows` partial rows (used by the fused bias-gradient epilogues of the GEMM / attention)
+int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st) {
+  return finalize(part, nrows, N, out, accumulate, nullptr, 0, nullptr, 0, st);
+}
+
 extern "C" size_t nbest_rowred_ws_bytes(int64_t M, int64_t N) { return (size_t)3 * rowred_blocks(M) * N * sizeof(float); }
 extern "C" size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H) {
   return nbest_rowred_ws_bytes(M, H) + (size_t)M * H * sizeof(float);

@@ -17,7 +17,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_DGELU, EPI_RES, EPI_F3
 
 EXPORTS = [
     "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes",
-    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_layernorm_fwd",
+    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step",
     "nbest_cast_f32_to_bf16", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
@@ -31,7 +31,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64), ("ldu", C.c_int64),
                 ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("dtype", C.c_int32),
-                ("accumulate", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64)]
+                ("accumulate", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64),
+                ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("pad_", C.c_int32)]
 
 
 class LabelSpaceC(C.Structure):
@@ -74,6 +75,7 @@ def lib():
             if not hasattr(L, name):
                 raise RuntimeError("nbest_amd: %s does not export %s" % (LIB_PATH, name))
         for name in ("nbest_embed_bwd_ws_bytes", "nbest_gemm_ws_bytes", "nbest_rowred_ws_bytes", "nbest_heads_ws_bytes",
+                     "nbest_attention_bwd_ws_bytes",
                      "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         L.nbest_embed_bwd_ws_bytes.argtypes = [C.c_int64, C.c_int64]
@@ -87,7 +89,8 @@ def lib():
         L.nbest_embed_ln_fwd.argtypes = [vp] * 10 + [i64, i32, f32, i32, f32, u64, u32, vp]
         L.nbest_embed_ln_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, i32, i64, i64, i32, f32, u64, u32, vp, sz, vp]
         L.nbest_attention_fwd.argtypes = [vp] * 4 + [i32] * 5 + [f32, u64, u32, vp]
-        L.nbest_attention_bwd.argtypes = [vp] * 6 + [i32] * 5 + [f32, u64, u32, vp]
+        L.nbest_attention_bwd.argtypes = [vp] * 7 + [i32, vp, sz] + [i32] * 5 + [f32, u64, u32, vp]
+        L.nbest_attention_bwd_ws_bytes.argtypes = [i32, i32, i32]
         L.nbest_layernorm_fwd.argtypes = [vp] * 5 + [i64, i32, f32, i32, vp]
         L.nbest_layernorm_bwd.argtypes = [vp] * 9 + [i64, i32, i32, i32, f32, u64, u32, vp, sz, vp]
         L.nbest_colsum.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, sz, vp]
@@ -139,7 +142,7 @@ def _ws(nbytes, device):
 # thin per-op wrappers (used by the kernel parity tests; training goes through encoder_forward/backward)
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=None, R=None, U=None, out=None,
-         accumulate=False, drop_p=0.0, seed=0, drop_stream=0):
+         accumulate=False, drop_p=0.0, seed=0, drop_stream=0, colsum_out=None):
     """C[M,N] = epi(op(A) . op(B)); returns C (and U for EPI_BIAS_GELU)."""
     dt = dtype_code(A.dtype)
     dev = A.device
@@ -158,6 +161,7 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=No
     g.ldu = U.stride(0) if U is not None else 0
     g.trans_a, g.trans_b, g.epilogue, g.dtype = int(trans_a), int(trans_b), epilogue, dt
     g.accumulate, g.drop_p, g.drop_stream, g.seed = int(accumulate), drop_p, drop_stream, seed
+    g.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
     nb = lib().nbest_gemm_ws_bytes(C.byref(g))
     ws = _ws(nb, dev)
     g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
@@ -207,10 +211,12 @@ def attention_fwd(qkv, key_mask, B, S, heads, drop_p=0.0, seed=0, drop_stream=0)
     return ctx, lse
 
 
-def attention_bwd(qkv, key_mask, ctx, dctx, lse, B, S, heads, drop_p=0.0, seed=0, drop_stream=0):
+def attention_bwd(qkv, key_mask, ctx, dctx, lse, B, S, heads, drop_p=0.0, seed=0, drop_stream=0, dbias=None):
     dqkv = torch.empty_like(qkv)
-    check(lib().nbest_attention_bwd(ptr(qkv), ptr(key_mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), B, S, heads, 64,
-                                    dtype_code(qkv.dtype), drop_p, seed, drop_stream, stream_ptr()), "attention_bwd")
+    ws = _ws(lib().nbest_attention_bwd_ws_bytes(B, S, heads), qkv.device) if dbias is not None else None
+    check(lib().nbest_attention_bwd(ptr(qkv), ptr(key_mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), 0, ptr(ws),
+                                    ws.numel() if ws is not None else 0, B, S, heads, 64, dtype_code(qkv.dtype), drop_p, seed,
+                                    drop_stream, stream_ptr()), "attention_bwd")
     return dqkv
 
 

@@ -71,7 +71,9 @@ def test_gemm_layouts_and_epilogues(dtype, ta, tb):
     close(tag + " bias_res", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_BIAS_DROP_RES, bias=bias, R=R), ref + bias + R.float(), tol)
     close(tag + " res", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_RES, R=R), ref + R.float(), tol)
     Uin = rnd(M, N, dtype=dtype, seed=5)
-    close(tag + " dgelu", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_DGELU, U=Uin), ref * dgelu(Uin.float()), tol)
+    cs = torch.zeros(N, device=DEV)
+    close(tag + " dgelu", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_DGELU, U=Uin, colsum_out=cs), ref * dgelu(Uin.float()), tol)
+    close(tag + " dgelu fused column sums", cs, (ref * dgelu(Uin.float())).sum(0), 5 * tol)
     got = hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_F32_SPLITK)
     assert got.dtype == torch.float32
     close(tag + " f32_splitk", got, ref, tol)
@@ -202,7 +204,9 @@ def test_attention_fwd_bwd(dtype, S):
     close("attn_fwd lse", lse, lse_ref, tol)
     dctx = rnd(B * S, H, dtype=dtype, seed=62)
     ref.backward(dctx.float())
-    dqkv = hb.attention_bwd(qkv, mask, ctx, dctx, lse, B, S, heads)
+    dbias = torch.zeros(3 * H, device=DEV)
+    dqkv = hb.attention_bwd(qkv, mask, ctx, dctx, lse, B, S, heads, dbias=dbias)
+    close("attn_bwd fused bias grad %s S=%d" % (dtype, S), dbias, qr.grad.sum(0), 5 * tol)
     d, r = dqkv.float().reshape(B * S, 3, H), qr.grad.reshape(B * S, 3, H)
     for i, nm in enumerate("QKV"):
         close("attn_bwd d%s %s S=%d" % (nm, dtype, S), d[:, i], r[:, i], 2 * tol)
