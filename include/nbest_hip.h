@@ -75,9 +75,9 @@ size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H);
 enum {
   NBEST_EPI_NONE = 0,          /* C = acc                                                    */
   NBEST_EPI_BIAS = 1,          /* C = acc + bias[n]                                          */
-  NBEST_EPI_BIAS_GELU = 2,     /* U = acc + bias[n] ; C = gelu_erf(U)      (U and C stored)  */
+  NBEST_EPI_BIAS_GELU = 2,     /* u = acc + bias[n]; C = gelu_erf(u); U = gelu'(u) (both stored) */
   NBEST_EPI_BIAS_DROP_RES = 3, /* C = drop(acc + bias[n]) + R[m,n]                           */
-  NBEST_EPI_DGELU = 4,         /* C = acc * gelu'(U[m,n])                                    */
+  NBEST_EPI_DGELU = 4,         /* C = acc * U[m,n]   (U = gelu'(u) saved by BIAS_GELU)       */
   NBEST_EPI_RES = 5,           /* C = acc + R[m,n]                                           */
   NBEST_EPI_F32_SPLITK = 6     /* Cf32[N x ...] = sum over K-splits (weight gradient), fp32  */
 };
@@ -87,7 +87,7 @@ typedef struct nbest_gemm_args {
   void* C;            /* dtype output (or fp32 when epilogue == NBEST_EPI_F32_SPLITK)          */
   const float* bias;  /* [N] or NULL                                                          */
   const void* R;      /* residual [M][ldr], dtype                                             */
-  void* U;            /* pre-activation [M][ldu], dtype: written by BIAS_GELU, read by DGELU   */
+  void* U;            /* GELU derivative [M][ldu], dtype: written by BIAS_GELU, read by DGELU */
   void* ws;           /* split-K slabs: >= nbest_gemm_ws_bytes(args)                           */
   size_t ws_bytes;
   int64_t M, N, K;

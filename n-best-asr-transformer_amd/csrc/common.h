@@ -124,7 +124,7 @@ __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erf
 __device__ __forceinline__ float dgelu_f(float u) {
   // d/du [u * Phi(u)] = Phi(u) + u * phi(u)
   const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * u * u);
   return cdf + u * pdf;
 }
 

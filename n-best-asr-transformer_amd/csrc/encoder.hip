@@ -7,7 +7,7 @@
 //   X[0..L]   [M][H] T      X[0] = embedding output, X[l+1] = output of layer l
 //   emb_stats [M][2] f32
 //   per layer: qkv [M][3H] T | ctx [M][H] T | lse [B*heads*S] f32 | r1 [M][H] T | st1 [M][2] f32 |
-//              x1 [M][H] T | u [M][F] T | hact [M][F] T | r2 [M][H] T | st2 [M][2] f32
+//              x1 [M][H] T | u = gelu'(pre-activation) [M][F] T | hact [M][F] T | r2 [M][H] T | st2 [M][2] f32
 // Scratch `ws` (backward): dR | dRd | dB1 | dctx [M][H] T, dBig [M][F] T, dqkv [M][3H] T,
 //              column-reduction partials, split-K slabs, embedding-backward buffer.
 #include "common.h"
@@ -171,7 +171,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     RUN(gemm(dt, ctx, P.W(o.wo), r1, M, H, H, H, H, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), H, nullptr, 0, nullptr, 0, 0,
              d->hidden_drop, d->seed, s0 + 1, st));
     RUN(nbest_layernorm_fwd(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, st1, M, H, d->ln_eps, dt, stream));
-    // FFN up + bias + GELU (pre-activation kept for the backward)
+    // FFN up + bias + GELU (GELU' of the pre-activation kept for the backward)
     RUN(gemm(dt, x1, P.W(o.w1), hact, M, F, H, H, H, F, 0, 0, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, 0, u, F, nullptr, 0, 0, 0.f,
              0, 0, st));
     // FFN down + dropout + residual, then LayerNorm

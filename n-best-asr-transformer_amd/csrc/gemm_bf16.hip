@@ -200,9 +200,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
       for (int e = 0; e < 4; ++e) { v[e] += pb0[e]; v[4 + e] += pb1[e]; }
     }
     if (EPI == NBEST_EPI_BIAS_GELU) {
-      Vec8<bf16>::store(p.U + m * p.ldu + n8, v);
+      float gp[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+      for (int e = 0; e < 8; ++e) {
+        float cdf, ex;
+        gelu_parts_fast(v[e], cdf, ex);
+        gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
+        v[e] *= cdf;
+      }
+      Vec8<bf16>::store(p.U + m * p.ldu + n8, gp);
     }
     if (EPI == NBEST_EPI_BIAS_DROP_RES) {
       if (p.drop.thr16) {
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     if (EPI == NBEST_EPI_DGELU) {
       const bf16x8 u = __builtin_bit_cast(bf16x8, pre[it]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= dgelu_fast((float)u[e]);
+      for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
     }
     Vec8<bf16>::store((bf16*)p.C + m * p.ldc + n8, v);
     if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {

@@ -20,6 +20,8 @@
 //     whole-line I/O, fast erf) but in 32-row chunks, with the residual / pre-activation rows of the
 //     next chunk prefetched while the current one is processed.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -40,12 +42,12 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 }
 
 // one operand tile: ROWS x 32 bf16 = ROWS*4 16-byte chunks, 256 threads -> ROWS/64 DMA instructions per thread
-template <bool TR, int ROWS>
+template <bool TR, int ROWS, int NT>
 __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid) {
   const int wave = tid >> 6;
 #pragma unroll
-  for (int i = 0; i < ROWS / 64; ++i) {
-    const int p = i * 256 + tid;
+  for (int i = 0; i < ROWS * 4 / NT; ++i) {
+    const int p = i * NT + tid;
     uint32_t voff;
     if (!TR) {
       const int row = p >> 2, slot = p & 3;
@@ -57,7 +59,7 @@ __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* til
       const int mc = slot ^ (2 * (krow & 3) + 8 * ((krow >> 3) & 1));
       voff = (uint32_t)(((k0 + krow) * ld + row0 + mc * 8) * 2);
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * 256 + wave * 64) * 16), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, voff, 0, 0, 0);
   }
 }
 
@@ -86,6 +88,8 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* tile, int row_base, int
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -94,17 +98,18 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else static_assert(N < 0, "add the literal");
 }
 
-template <int BM, int BN, int STAGES, bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
+template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr bool PIPE = (BM == 128);   // second fragment register set: fits only the 64x64 wave tile
-  constexpr int WTM = BM / 2, WTN = BN / 2;          // 2 x 2 waves
+  constexpr int NT = WM * WN * 64;                   // 256 threads (2 x 2 waves) or 512 (2 x 4 waves)
+  constexpr bool PIPE = (BM == 128 && NT == 256);   // second fragment register set: fits only the 64x64 wave tile
+  constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TMt = WTM / 16, TNt = WTN / 16;
   static_assert(WTN == 64, "row-contiguous epilogue assumes 64-column wave tiles");
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int NDMA = BM / 64 + BN / 64;            // LDS-DMA instructions per thread and stage
+  constexpr int NDMA = (BM + BN) * 4 / NT;           // LDS-DMA instructions per thread and stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int nwg = gridDim.x;
   const int id = xcd_remap2(blockIdx.x, nwg);
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
   const int64_t eld = kHasR ? p.ldr : p.ldu;
   f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
   if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
-  i32x4 pre[2][4];
+  i32x4 pre[TMt / 2][4];   // chunk 0 is fetched before the K loop, the others right after it (fragment registers are dead then)
   if (kPre) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -145,14 +150,75 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
     for (int j = 0; j < TNt; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  if constexpr (PIPE) {
+  if constexpr (NT == 512) {
+    // ---- ping-pong (8 waves = 2 groups of one wave per SIMD): a group alternates a LOAD slot (fragment
+    // reads of stage j, LDS-DMA of stage j+STAGES-1, counted vmcnt) with an MFMA slot (stage j); group 1
+    // runs one slot behind group 0, so on every SIMD one wave is always in its MFMA slot while the other
+    // feeds itself.  One workgroup-wide s_barrier per slot keeps the two groups out of phase.
+    const int grp = __builtin_amdgcn_readfirstlane(wm);   // provably wave-uniform: the guarded s_barrier must be a scalar branch
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0) {
+      if (s0 < nk) {
+        stage_tile2<TA, BM, NT>(rsA, lds + s0 * STAGE, m0, kbeg + (int64_t)s0 * BK, p.lda, tid);
+        stage_tile2<TB, BN, NT>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, p.ldb, tid);
+      }
+    }
+    {
+      const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
+      if (younger >= 2) wait_vm<2 * NDMA>();
+      else if (younger == 1) wait_vm<NDMA>();
+      else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();                 // stage 0 landed for everyone
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---------------- LOAD slot ----------------
+      if (kt + STAGES - 1 < nk) {
+        int nb = buf + STAGES - 1;
+        if (nb >= STAGES) nb -= STAGES;
+        const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
+        stage_tile2<TA, BM, NT>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+        stage_tile2<TB, BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+      }
+      const char* cur = lds + buf * STAGE;
+      bf16x8 af[TMt], bfr[TNt];
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<TB, BN>(cur + A_BYTES, wn * WTN + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < TMt; ++i) af[i] = read_frag2<TA, BM>(cur, wm * WTM + i * 16, lane);
+      {
+        // retire this wave's share of stage kt+1 (read by group 0 two slots from now)
+        const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1;   // stages kt+1.. outstanding
+        if (c >= 3) wait_vm<2 * NDMA>();
+        else if (c == 2) wait_vm<NDMA>();
+        else if (c == 1) wait_vm<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- MFMA slot ----------------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TMt; ++i)
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count
+  } else if constexpr (PIPE) {
   // ---- ring: buffers hold stages kt+1 .. kt+STAGES; fragments of stage kt+1 are read (into the other
   // register set) while the MFMAs of stage kt run, so no LDS round trip is exposed at a stage boundary.
 #pragma unroll
   for (int s = 0; s < STAGES; ++s) {
     if (s < nk) {
-      stage_tile2<TA, BM>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
-      stage_tile2<TB, BN>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+      stage_tile2<TA, BM, NT>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
+      stage_tile2<TB, BN, NT>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
     }
   }
   bf16x8 afA[TMt], bfA[TNt], afB[TMt], bfB[TNt];
@@ -184,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
     asm volatile("" ::: "memory");                                                                           \
     if (kt + STAGES < nk) {                                                                                  \
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES) * BK;                                                 \
-      stage_tile2<TA, BM>(rsA, lds + buf * STAGE, m0, k0, p.lda, tid);                                       \
-      stage_tile2<TB, BN>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, p.ldb, tid);                             \
+      stage_tile2<TA, BM, NT>(rsA, lds + buf * STAGE, m0, k0, p.lda, tid);                                       \
+      stage_tile2<TB, BN, NT>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, p.ldb, tid);                             \
     }                                                                                                        \
     const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;                                                      \
     if (kt + 1 < nk) {                                                                                       \
@@ -211,8 +277,8 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) {
     if (s < nk) {
-      stage_tile2<TA, BM>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
-      stage_tile2<TB, BN>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+      stage_tile2<TA, BM, NT>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
+      stage_tile2<TB, BN, NT>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
     }
   }
   int buf = 0;
@@ -228,8 +294,8 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
       int nb = buf + STAGES - 1;
       if (nb >= STAGES) nb -= STAGES;
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
-      stage_tile2<TA, BM>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-      stage_tile2<TB, BN>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+      stage_tile2<TA, BM, NT>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+      stage_tile2<TB, BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
     }
     const char* cur = lds + buf * STAGE;
     bf16x8 af[TMt], bfr[TNt];
@@ -246,19 +312,21 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
   }
 
   // ---- epilogue: 32-row chunks restaged through wave-private LDS ([32][64] fp32, chunk16 ^= row & 15) ----
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
   float* ep = (float*)lds + wave * 2048;
   float colacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (kPre) {
 #pragma unroll
-  for (int c = 0; c < TMt / 2; ++c) {
-    if (kPre && c + 1 < TMt / 2) {
+    for (int c = 1; c < TMt / 2; ++c)
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int64_t m = erow0 + (c + 1) * 32 + it * 8;
-        pre[(c + 1) & 1][it] = (m < p.M) ? *(const i32x4*)(esrc + m * eld + en8) : i32x4{0, 0, 0, 0};
+        const int64_t m = erow0 + c * 32 + it * 8;
+        pre[c][it] = (m < p.M) ? *(const i32x4*)(esrc + m * eld + en8) : i32x4{0, 0, 0, 0};
       }
-    }
+  }
+  __builtin_amdgcn_s_barrier();   // every wave has finished reading the operand ring
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < TMt / 2; ++c) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
       const int row = ii * 16 + (lane & 15);
@@ -290,9 +358,15 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
         for (int e = 0; e < 4; ++e) { v[e] += pb0[e]; v[4 + e] += pb1[e]; }
       }
       if (EPI == NBEST_EPI_BIAS_GELU) {
-        Vec8<bf16>::store(p.U + m * p.ldu + n8, v);
+        float gp[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        for (int e = 0; e < 8; ++e) {
+          float cdf, ex;
+          gelu_parts_fast(v[e], cdf, ex);
+          gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
+          v[e] *= cdf;
+        }
+        Vec8<bf16>::store(p.U + m * p.ldu + n8, gp);
       }
       if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
         const uint32_t base = (uint32_t)(m * p.N + n8);
@@ -301,14 +375,14 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
         for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
       }
       if (kHasR) {
-        const bf16x8 r = __builtin_bit_cast(bf16x8, pre[c & 1][it]);
+        const bf16x8 r = __builtin_bit_cast(bf16x8, pre[c][it]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
       }
       if (kHasUin) {
-        const bf16x8 u = __builtin_bit_cast(bf16x8, pre[c & 1][it]);
+        const bf16x8 u = __builtin_bit_cast(bf16x8, pre[c][it]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= dgelu_fast((float)u[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
       }
       Vec8<bf16>::store((bf16*)p.C + m * p.ldc + n8, v);
       if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {
@@ -326,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmP2 p) {
       colacc[e] = x;
     }
     if ((lane >> 3) == 0) {
-      float* o = p.colpart + ((int64_t)tile_m * 2 + wm) * p.N + en8;
+      float* o = p.colpart + ((int64_t)tile_m * WM + wm) * p.N + en8;
       *(f32x4*)o = f32x4{colacc[0], colacc[1], colacc[2], colacc[3]};
       *(f32x4*)(o + 4) = f32x4{colacc[4], colacc[5], colacc[6], colacc[7]};
     }
@@ -350,20 +424,47 @@ struct Plan {
   int64_t kps;
 };
 
+// NBEST_TILE=256x256 | 256x128 | 128x128 forces a tile (experiments); default: per-shape choice
+static int forced_tile() {
+  static const int v = [] {
+    const char* e = getenv("NBEST_TILE");
+    if (!e) return 0;
+    if (!strcmp(e, "256x256")) return 3;
+    if (!strcmp(e, "128x256")) return 4;
+    if (!strcmp(e, "256x128")) return 2;
+    if (!strcmp(e, "128x128")) return 1;
+    return 0;
+  }();
+  return v;
+}
+
 static Plan make_plan(const nbest_gemm_args* a) {
   Plan pl;
   pl.bn = 128;
   // 256x128 where it fills the chip (two workgroups per CU -> 512 slots) and is not a weight gradient
   const int64_t t256 = ((a->M + 255) / 256) * (a->N / 128);
   pl.bm = (!a->trans_a && t256 >= 1024) ? 256 : 128;
+  const int ft = forced_tile();
+  const bool ok256 = (a->N % 256 == 0) && (!a->trans_a || a->M % 256 == 0);
+  if (ft == 3 && ok256) { pl.bm = 256; pl.bn = 256; }
+  else if (ft == 4 && ok256) { pl.bm = 128; pl.bn = 256; }
+  else if (ft == 2 && !a->trans_a) { pl.bm = 256; pl.bn = 128; }
+  else if (ft == 1) { pl.bm = 128; pl.bn = 128; }
+  else if (ft == 0 && !a->trans_a && !a->trans_b && a->N % 256 == 0 && ((a->M + 255) / 256) * (a->N / 256) >= 1024) {
+    pl.bm = 256; pl.bn = 256;   // ping-pong schedule: best for k-contiguous operands on the wide GEMMs (QKV, FFN-up forward)
+  }
   const int64_t tiles = ((a->M + pl.bm - 1) / pl.bm) * (a->N / pl.bn);
+  const int64_t slots = (pl.bn == 256) ? 256 : 512;   // workgroups resident at once
   int64_t splits = 1;
   if (a->epilogue == NBEST_EPI_F32_SPLITK) {
-    splits = (1024 + tiles - 1) / tiles;
-    const int64_t maxs = (a->K + 511) / 512;
-    if (splits > maxs) splits = maxs;
-    if (splits > 32) splits = 32;
-    if (splits < 1) splits = 1;
+    const int64_t maxs = (a->K / 512 < 1) ? 1 : ((a->K / 512 > 32) ? 32 : a->K / 512);
+    double best = -1.0;
+    for (int64_t sp = 1; sp <= maxs; ++sp) {
+      const int64_t blocks = tiles * sp;
+      const double eff = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
+      if (eff > best + 1e-9) { best = eff; splits = sp; }
+      if (blocks * 5 >= slots * 4 && eff >= 0.93) { splits = sp; break; }
+    }
   }
   int64_t k = (a->K + splits - 1) / splits;
   k = (k + 63) / 64 * 64;
@@ -372,13 +473,14 @@ static Plan make_plan(const nbest_gemm_args* a) {
   return pl;
 }
 
-template <int BM, int BN, int STAGES, bool TA, bool TB>
+template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB>
 static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
   constexpr int lds_bytes = STAGES * (BM + BN) * BK * 2;
+  constexpr int NT = WM * WN * 64;
 #define L(E)                                                                                                        \
   case E:                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, STAGES, TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-    gemm2_kernel<BM, BN, STAGES, TA, TB, E><<<grid, 256, lds_bytes, st>>>(p);                                        \
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E><<<grid, NT, lds_bytes, st>>>(p);                                 \
     break;
   switch (epi) {
     L(NBEST_EPI_NONE) L(NBEST_EPI_BIAS) L(NBEST_EPI_BIAS_GELU) L(NBEST_EPI_BIAS_DROP_RES) L(NBEST_EPI_DGELU)
@@ -396,7 +498,7 @@ static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
 
 // v2 is only faster with its 256x128 tile (measured: +8..14 % on the wide-N forward / dgrad GEMMs); the
 // 128x128 BK=32 ring loses to v1's 128x128 BK=64 (half the MFMAs per barrier and per DMA instruction)
-bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a) { return make_plan(a).bm == 256; }
+bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a) { return make_plan(a).bm == 256 || forced_tile() != 0; }   // 256x128 ring or 256x256 ping-pong
 
 int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
 
@@ -452,13 +554,21 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
              "gemm: split-K workspace too small (%zu < %zu)", a->ws_bytes, (size_t)p.splits * a->M * a->N * sizeof(float));
   const int grid = p.tiles_m * p.tiles_n * p.splits;
   int rc;
-  if (pl.bm == 256) {
-    if (!a->trans_b) rc = launch2<256, 128, 3, false, false>(p, epi, grid, st);
-    else rc = launch2<256, 128, 3, false, true>(p, epi, grid, st);
+  if (pl.bm == 128 && pl.bn == 256) {
+    if (!a->trans_a && !a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, false>(p, epi, grid, st);
+    else if (!a->trans_a && a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, true>(p, epi, grid, st);
+    else rc = launch2<128, 256, 2, 4, 4, true, true>(p, epi, grid, st);
+  } else if (pl.bm == 256 && pl.bn == 256) {
+    if (!a->trans_a && !a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, false>(p, epi, grid, st);
+    else if (!a->trans_a && a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, true>(p, epi, grid, st);
+    else rc = launch2<256, 256, 2, 4, 4, true, true>(p, epi, grid, st);
+  } else if (pl.bm == 256) {
+    if (!a->trans_b) rc = launch2<256, 128, 2, 2, 3, false, false>(p, epi, grid, st);
+    else rc = launch2<256, 128, 2, 2, 3, false, true>(p, epi, grid, st);
   } else {
-    if (!a->trans_a && !a->trans_b) rc = launch2<128, 128, 4, false, false>(p, epi, grid, st);
-    else if (!a->trans_a && a->trans_b) rc = launch2<128, 128, 4, false, true>(p, epi, grid, st);
-    else rc = launch2<128, 128, 4, true, true>(p, epi, grid, st);
+    if (!a->trans_a && !a->trans_b) rc = launch2<128, 128, 2, 2, 4, false, false>(p, epi, grid, st);
+    else if (!a->trans_a && a->trans_b) rc = launch2<128, 128, 2, 2, 4, false, true>(p, epi, grid, st);
+    else rc = launch2<128, 128, 2, 2, 4, true, true>(p, epi, grid, st);
   }
   if (rc) return rc;
   if (p.colpart) return nbest_internal_partial_rows_sum(p.colpart, p.tiles_m * 2, (int)a->N, a->colsum_out, a->colsum_accumulate, st);

@@ -71,13 +71,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p) {
         continue;
       }
       if (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES) v += p.bias[n];
-      if (EPI == NBEST_EPI_BIAS_GELU) { p.U[m * p.ldu + n] = v; v = gelu_f(v); }
+      if (EPI == NBEST_EPI_BIAS_GELU) { p.U[m * p.ldu + n] = dgelu_f(v); v = gelu_f(v); }
       if (EPI == NBEST_EPI_BIAS_DROP_RES) {
         if (p.drop.thr16) v = nb_keep(p.drop, (uint32_t)(m * p.N + n)) ? v * p.drop.scale : 0.f;
         v += p.R[m * p.ldr + n];
       }
       if (EPI == NBEST_EPI_RES) v += p.R[m * p.ldr + n];
-      if (EPI == NBEST_EPI_DGELU) v *= dgelu_f(p.U[m * p.ldu + n]);
+      if (EPI == NBEST_EPI_DGELU) v *= p.U[m * p.ldu + n];
       p.C[m * p.ldc + n] = v;
     }
   }

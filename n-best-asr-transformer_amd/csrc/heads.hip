@@ -168,73 +168,68 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
   }
 }
 
-// dWh[r][h] = sum_b dz[b][r] * drop(cls[b][h]); dbh[r] = sum_b dz[b][r].  grid R, block 256: the four
-// waves split the batch (b = wave, wave+4, ..), a lane owns columns lane, lane+64, ..; fixed-order LDS reduce
+// dWh[r][h] = sum_b dz[b][r] * drop(cls[b][h]); dbh[r] = sum_b dz[b][r].  grid (R, ceil(H/64)), block 256:
+// a block owns one head row x 64 columns (lane = column), its four waves split the batch; thousands of
+// short waves hide the load latency that a few long ones could not.  Fixed-order LDS reduce (deterministic).
 __global__ __launch_bounds__(256) void heads_wgrad_kernel(const float* __restrict__ cls, const float* __restrict__ dz,
                                                           const int32_t* __restrict__ head_row, int n_top, int B, int R, int H,
                                                           float* __restrict__ dWh, float* __restrict__ dbh, int accumulate,
                                                           DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][H] + [4]
-  const int r = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  __shared__ float redb[4];
+  const int r = blockIdx.x, h = blockIdx.y * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
   const int lay = layer_of_row(r, head_row, n_top, nullptr);
-  constexpr int MAXC = 32;  // H <= 2048
-  float acc[MAXC];
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) acc[i] = 0.f;
-  float sb = 0.f;
-  const int nc = (H + 63) / 64;
-  for (int b = wave; b < B; b += 4) {
-    const float g = dz[(int64_t)b * R + r];
-    sb += g;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int h = lane + 64 * i;
-      if (i < nc && h < H) {
-        float xv = cls[(int64_t)b * H + h];
-        if (drop.thr16) xv = nb_keep(drop, (uint32_t)((lay * B + b) * H + h)) ? xv * drop.scale : 0.f;
-        acc[i] = fmaf(g, xv, acc[i]);
-      }
+  float acc = 0.f, sb = 0.f;
+  if (h < H) {
+#pragma unroll 4
+    for (int b = wave; b < B; b += 4) {
+      const float g = dz[(int64_t)b * R + r];
+      float xv = cls[(int64_t)b * H + h];
+      if (drop.thr16) xv = nb_keep(drop, (uint32_t)((lay * B + b) * H + h)) ? xv * drop.scale : 0.f;
+      acc = fmaf(g, xv, acc);
+      sb += g;
     }
   }
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int h = lane + 64 * i;
-    if (i < nc && h < H) red[wave * H + h] = acc[i];
-  }
-  if (lane == 0) red[4 * H + wave] = sb;
+  red[wave][threadIdx.x & 63] = acc;
+  if ((threadIdx.x & 63) == 0) redb[wave] = sb;
   __syncthreads();
-  for (int h = threadIdx.x; h < H; h += blockDim.x) {
-    const float v = (red[h] + red[H + h]) + (red[2 * H + h] + red[3 * H + h]);
+  if (wave == 0 && h < H) {
+    const int l = threadIdx.x;
+    const float v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
     float* o = dWh + (int64_t)r * H + h;
     *o = accumulate ? *o + v : v;
   }
-  if (threadIdx.x == 0) {
-    const float v = (red[4 * H] + red[4 * H + 1]) + (red[4 * H + 2] + red[4 * H + 3]);
+  if (threadIdx.x == 0 && blockIdx.y == 0) {
+    const float v = (redb[0] + redb[1]) + (redb[2] + redb[3]);
     dbh[r] = accumulate ? dbh[r] + v : v;
   }
 }
 
-// dcls[b][h] = sum_r dz[b][r] * Wh[r][h] * dropmask_{layer(r)}(b,h).  grid B, block 256
+// dcls[b][h] = sum_r dz[b][r] * Wh[r][h] * dropmask_{layer(r)}(b,h).  grid (B, ceil(H/64)), block 256: waves split r
 __global__ __launch_bounds__(256) void heads_dgrad_kernel(const float* __restrict__ Wh, const float* __restrict__ dz,
                                                           const int32_t* __restrict__ head_row, int n_top, int R, int H,
                                                           float* __restrict__ dcls, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // dz row [R] | layer of row [R] (as float)
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // dz row [R] | layer of row [R] | red [4][64]
   const int b = blockIdx.x, B = gridDim.x;
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y * 64 + l;
+  float* red = sh + 2 * R;
   for (int r = threadIdx.x; r < R; r += blockDim.x) {
     sh[r] = dz[(int64_t)b * R + r];
     sh[R + r] = (float)layer_of_row(r, head_row, n_top, nullptr);
   }
   __syncthreads();
-  for (int h = threadIdx.x; h < H; h += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) {
+  float s = 0.f;
+  if (h < H) {
+#pragma unroll 4
+    for (int r = wave; r < R; r += 4) {
       float w = Wh[(int64_t)r * H + h];
       if (drop.thr16) w = nb_keep(drop, (uint32_t)(((int)sh[R + r] * B + b) * H + h)) ? w * drop.scale : 0.f;
-      s += sh[r] * w;
+      s = fmaf(sh[r], w, s);
     }
-    dcls[(int64_t)b * H + h] = s;
   }
+  red[wave * 64 + l] = s;
+  __syncthreads();
+  if (wave == 0 && h < H) dcls[(int64_t)b * H + h] = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
 }
 
 template <typename T>
@@ -322,9 +317,9 @@ extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const flo
   loss_reduce_kernel<<<1, 256, 0, st>>>(sloss, B, loss_parts);
   NB_LAUNCH_CHECK();
   if (need_grad) {
-    heads_wgrad_kernel<<<R, 256, ((size_t)4 * H + 4) * sizeof(float), st>>>(cls, dz, ls->head_row, n_top, B, R, H, dWh, dbh, accumulate, d);
+    heads_wgrad_kernel<<<dim3(R, (H + 63) / 64), 256, 0, st>>>(cls, dz, ls->head_row, n_top, B, R, H, dWh, dbh, accumulate, d);
     NB_LAUNCH_CHECK();
-    heads_dgrad_kernel<<<B, 256, (size_t)2 * R * sizeof(float), st>>>(Wh, dz, ls->head_row, n_top, R, H, dcls, d);
+    heads_dgrad_kernel<<<dim3(B, (H + 63) / 64), 256, ((size_t)2 * R + 256) * sizeof(float), st>>>(Wh, dz, ls->head_row, n_top, R, H, dcls, d);
     NB_LAUNCH_CHECK();
   }
   return NBEST_OK;
