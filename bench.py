@@ -27,6 +27,9 @@ from nbest_amd.optim import HipBertAdam
 from nbest_amd.trainer import GradReducer, broadcast_parameters, init_distributed, train_step
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X (MI355X_MICROARCH.md)
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+# KiB -> bytes), measured on configs[1]; see profiles/README.md.  None until measured.
+TRAFFIC_BYTES_PER_LAUNCH = 416.5e6   # (2 x 175 430 KiB FETCH_SIZE + 55 874 KiB WRITE_SIZE) x 1024, avg of the layer's 4 launches
 
 
 def flops_per_utt(cfg, S, St=0):
@@ -66,25 +69,33 @@ def cpu_baseline(labels, seconds_budget=25.0):
                 sample="%d steps of bert-base fp32 B=8 S=128 n_best=5 (fwd+loss+bwd+BertAdam), oracle on CPU" % n)
 
 
-def time_dominant_kernel(M, H, F, iters=20):
-    """FFN-up forward GEMM [M,H]x[F,H]^T + bias + GELU (gemm_bf16_kernel<0,0,BIAS_GELU>): avg launch duration
-    by HIP events on the launch stream"""
+def time_dominant_kernel(M, H, F, iters=10):
+    """The kernel with the largest share of the step (rocprof: profiles/): the weight-gradient GEMM
+    gemm_bf16_kernel<true,true,F32_SPLITK> (dW = dY^T . X over the M = B*S token rows, split-K, fp32 out).
+    It is launched four times per layer (QKV, attention-out, FFN-up, FFN-down); this times that set on the
+    launch stream with HIP events and returns (avg ms per launch, avg algorithmic flops per launch,
+    avg algorithmic bytes per launch = both bf16 operands read once + the fp32 gradient written once)."""
     dev = "cuda"
-    x = (torch.randn(M, H, device=dev) * 0.5).bfloat16()
-    w = (torch.randn(F, H, device=dev) * 0.03).bfloat16()
-    bias = torch.randn(F, device=dev) * 0.02
-    out = torch.empty(M, F, dtype=torch.bfloat16, device=dev)
-    U = torch.empty_like(out)
-    for _ in range(3):
-        hb.gemm(x, w, M, F, H, epilogue=hb.EPI_BIAS_GELU, bias=bias, out=out, U=U)
+    r = lambda *s: (torch.randn(*s, device=dev) * 0.5).bfloat16()
+    x, big = r(M, H), r(M, F)
+    shapes = [(3 * H, H, r(M, 3 * H), x), (H, H, r(M, H), x), (F, H, big, x), (H, F, r(M, H), big)]
+    outs = [torch.empty(n, k, dtype=torch.float32, device=dev) for n, k, _, _ in shapes]
+
+    def once():
+        for (n, k, dy, a), o in zip(shapes, outs):
+            hb.gemm(dy, a, n, k, M, 1, 1, hb.EPI_F32_SPLITK, out=o, defer_reduce=True)   # the GEMM kernel alone
+    for _ in range(2):
+        once()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        hb.gemm(x, w, M, F, H, epilogue=hb.EPI_BIAS_GELU, bias=bias, out=out, U=U)
+        once()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    return ms, 2.0 * M * F * H
+    ms = e0.elapsed_time(e1) / (iters * len(shapes))
+    flops = sum(2.0 * M * n * k for n, k, _, _ in shapes) / len(shapes)
+    byts = sum(2.0 * M * (n + k) + 4.0 * n * k for n, k, _, _ in shapes) / len(shapes)
+    return ms, flops, byts
 
 
 def note(msg):
@@ -176,13 +187,13 @@ def main():
             "last_loss_per_utt": round(loss / a.batch, 4),
         }
         if a.dtype == "bf16":
-            ms, fl = time_dominant_kernel(a.batch * a.seq_len, cfg.hidden_size, cfg.intermediate_size)
+            ms, fl, by = time_dominant_kernel(a.batch * a.seq_len, cfg.hidden_size, cfg.intermediate_size)
             ach = fl / (ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                               "kernel": "gemm_bf16_kernel<false,false,BIAS_GELU> (FFN-up fwd, M=%d N=%d K=%d)" % (
-                                   a.batch * a.seq_len, cfg.intermediate_size, cfg.hidden_size),
-                               "avg_launch_ms": round(ms, 4), "flops_per_launch": fl}
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                               "kernel": "gemm_bf16_kernel<true,true,F32_SPLITK> (weight gradients dW = dY^T.X, K = %d token rows; "
+                                         "avg over the 4 launches of a layer: 2304x768, 768x768, 3072x768, 768x3072)" % (a.batch * a.seq_len),
+                               "avg_launch_ms": round(ms, 4), "flops_per_launch": fl, "algorithmic_bytes_per_launch": by}
         if world == 1 and not a.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")
             res["cpu_baseline"] = cpu_baseline(labels)

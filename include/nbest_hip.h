@@ -103,8 +103,10 @@ typedef struct nbest_gemm_args {
                                gradient of the layer that produced A; fused into the epilogue (not for
                                F32_SPLITK).  Needs ws >= nbest_gemm_ws_bytes().                            */
   int32_t colsum_accumulate; /* colsum_out += instead of = */
-  int32_t pad_;
+  int32_t flags;             /* NBEST_GEMM_DEFER_REDUCE: F32_SPLITK leaves the per-split partial slabs in ws
+                                (layout [splits][M][N] fp32) and does NOT launch the reduce; C is untouched */
 } nbest_gemm_args;
+#define NBEST_GEMM_DEFER_REDUCE 1
 size_t nbest_gemm_ws_bytes(const nbest_gemm_args* a);
 int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream);
 

@@ -18,6 +18,7 @@
 //             of the 32x32x16 operand AND for the 4-row transposed reads.
 // fp32 path (parity/debug): one thread per query row, plain VALU math, any S <= 512.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -125,15 +126,17 @@ __global__ __launch_bounds__(128) void attn_bwd_f32_kernel(const float* __restri
 // bf16 MFMA kernels
 // =================================================================================================
 // LDS-DMA a [Sp rows][64] bf16 tile (rows = tokens of one sequence, 64 columns starting at col_off)
-__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rs, char* tile, int Sp, int col_off, int ld, int tid) {
+__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rs, char* tile, int Sp, int col_off, int ld, int tid, int nt = 256) {
   const int wave = tid >> 6;
-  const int iters = Sp >> 5;  // Sp*8 chunks / 256 threads
+  const int chunks = Sp * 8;                    // 16-byte chunks (a multiple of 256: whole waves are in or out)
+  const int iters = (chunks + nt - 1) / nt;
   for (int i = 0; i < iters; ++i) {
-    const int p = i * 256 + tid;
+    const int p = i * nt + tid;
+    if (p >= chunks) break;
     const int row = p >> 3, slot = p & 7;
     const int c = slot ^ gsw(row);
     const uint32_t voff = (uint32_t)((row * ld + col_off + c * 8) * 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * 256 + wave * 64) * 16), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * nt + wave * 64) * 16), 16, voff, 0, 0, 0);
   }
 }
 
@@ -436,6 +439,177 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16* __restri
   }
 }
 
+// ---- backward, second structure: S <= 256, small LDS footprint -----------------------------------------
+// One wave per 32-key block (4 waves for S <= 128, 8 for S <= 256).  LDS: Qt | Kt | dOt ([Sp][64] bf16) and a
+// DOUBLE-BUFFERED dS slab of ONE query block ([32 q][Sp keys]); V fragments come straight from HBM into
+// registers (row fragments are 16 contiguous bytes per lane).  After the barrier that completes the slab of
+// query block qb, wave (qb mod NW) turns it into dQ[qb] = dS . K while everybody proceeds with qb+1.
+// 65 KiB at S = 128 -> two workgroups per CU; 130 KiB at S = 256.
+template <int NKB>
+__global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_kernel(
+    const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask, const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+    const float* __restrict__ lse, bf16* __restrict__ dqkv, float* __restrict__ colpart, int S, int heads, int H, float scale,
+    DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int Sp = NKB * 32;
+  constexpr int NW = (NKB <= 4) ? 4 : 8, NT = NW * 64;
+  constexpr int RS = (Sp <= 128) ? 256 : 512;         // dS slab row stride in bytes: a power of two (the XOR swizzle
+                                                       // permutes 16 chunks inside an aligned 256-byte group)
+  char* Qt = lds;
+  char* Kt = Qt + Sp * 128;
+  char* dOt = Kt + Sp * 128;
+  char* dSb = dOt + Sp * 128;                          // [2][32][RS]
+  float* lse_s = (float*)(dSb + 2 * 32 * RS);
+  float* del_s = lse_s + Sp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int ld = 3 * H;
+  const bf16* base = qkv + (int64_t)b * S * ld;
+  const bf16* dobase = dctx + (int64_t)b * S * H;
+  const bf16* obase = ctx + (int64_t)b * S * H;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(S * ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, (uint32_t)(S * H * 2), 0x00020000);
+  stage_rows(rs, Qt, Sp, h * 64, ld, tid, NT);
+  stage_rows(rs, Kt, Sp, H + h * 64, ld, tid, NT);
+  stage_rows(rsd, dOt, Sp, h * 64, H, tid, NT);
+  for (int k = tid; k < Sp; k += NT) lse_s[k] = (k < S) ? lse[(int64_t)bh * S + k] : INFINITY;
+  {  // delta[q] = sum_d dO[q][d] * O[q][d]; two threads per row
+    const int r = tid >> 1, half = tid & 1;
+    float sdel = 0.f;
+    if (r < S) {
+      const bf16* dp = dobase + (int64_t)r * H + h * 64 + 32 * half;
+      const bf16* op = obase + (int64_t)r * H + h * 64 + 32 * half;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a[8], o[8];
+        Vec8<bf16>::load(dp + 8 * c, a);
+        Vec8<bf16>::load(op + 8 * c, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sdel = fmaf(a[j], o[j], sdel);
+      }
+    }
+    sdel += __shfl_xor(sdel, 1, 64);
+    if (half == 0 && r < Sp) del_s[r] = sdel;
+  }
+  // this wave's key block: mask bit and V row fragments straight from HBM
+  const int key = 32 * wave + (lane & 31);
+  const bool kvalid = (wave < NKB) && key < S;
+  const float mk = (kvalid && mask[b * S + key]) ? 0.f : -INFINITY;
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const i32x4 raw = kvalid ? *(const i32x4*)(base + (int64_t)key * ld + 2 * H + h * 64 + 16 * ks + 8 * hh) : i32x4{0, 0, 0, 0};
+    vf[ks] = __builtin_bit_cast(bf16x8, raw);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave < NKB) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = row_frag(Kt, 32 * wave, ks, lane);
+  }
+  f32x16 dk0, dk1, dv0, dv1, dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dk0[r] = dk1[r] = dv0[r] = dv1[r] = dq0[r] = dq1[r] = 0.f;
+
+#pragma unroll 1
+  for (int qb = 0; qb < NKB; ++qb) {
+    char* slab = dSb + (qb & 1) * 32 * RS;
+    if (wave < NKB) {
+      f32x16 sa, da;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = da[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, 32 * qb, ks, lane), kf[ks], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOt, 32 * qb, ks, lane), vf[ks], da, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 l4 = *(const f32x4*)(lse_s + 32 * qb + 8 * r4 + 4 * hh);
+        const f32x4 d4 = *(const f32x4*)(del_s + 32 * qb + 8 * r4 + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * r4 + e;
+          const int ql = 8 * r4 + 4 * hh + e;           // query row inside the block
+          const int q = 32 * qb + ql;
+          const float pv = __expf(sa[r] * scale + mk - l4[e]);
+          float pt = pv, dp = da[r];
+          if (drop.thr16) {
+            const bool keep = nb_keep(drop, (uint32_t)((bh * S + q) * S + key));
+            pt = keep ? pv * drop.scale : 0.f;
+            dp = keep ? dp * drop.scale : 0.f;
+          }
+          const float ds = pv * (dp - d4[e]) * scale;
+          sa[r] = pt;
+          da[r] = ds;
+          *(bf16*)(slab + ql * RS + ((((key >> 3) ^ (ql & 15))) << 4) + (key & 7) * 2) = (bf16)ds;
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pa = acc_to_frag(sa, s2), dsa = acc_to_frag(da, s2);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(dOt, 32 * qb + 16 * s2, 0, lane), dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(dOt, 32 * qb + 16 * s2, 32, lane), dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, tr_frag<true>(Qt, 32 * qb + 16 * s2, 0, lane), dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, tr_frag<true>(Qt, 32 * qb + 16 * s2, 32, lane), dk1, 0, 0, 0);
+      }
+    }
+    __syncthreads();   // the dS slab of query block qb is complete (and slab (qb+1)&1 is free again)
+    if (wave == (qb % NW)) {
+#pragma unroll
+      for (int ks = 0; ks < 2 * NKB; ++ks) {
+        const int row = lane & 31;
+        const int c = 2 * ks + hh;
+        const bf16x8 dsf = *(const bf16x8*)(slab + row * RS + ((c ^ (row & 15)) << 4));
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 0, lane), dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 32, lane), dq1, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();  // everyone is done with Qt / Kt / dOt / slabs: reuse them as output images
+  if (colpart) {
+    float* cs = (float*)dSb;   // [NW][3][64]
+    const f32x16* tiles[6] = {&dq0, &dq1, &dk0, &dk1, &dv0, &dv1};
+#pragma unroll
+    for (int t6 = 0; t6 < 6; ++t6) {
+      float x = 0.f;
+      if (wave < NKB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x += (*tiles[t6])[r];
+      }
+      x += __shfl_xor(x, 32, 64);
+      if (lane < 32) cs[(wave * 3 + (t6 >> 1)) * 64 + (t6 & 1) * 32 + lane] = x;
+    }
+    __syncthreads();
+    if (tid < 192) {
+      const int which = tid >> 6, dcol = tid & 63;
+      float x = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) x += cs[(w2 * 3 + which) * 64 + dcol];
+      colpart[(int64_t)b * 3 * H + which * H + h * 64 + dcol] = x;
+    }
+  }
+  if (wave < NKB) {
+    const int r0 = 32 * wave;      // wave w holds dQ of query block w (w = qb mod NW, NKB <= NW) and dK/dV of key block w
+    bf16* g = dqkv + ((int64_t)b * S + r0) * ld + h * 64;
+    store_tile(Qt, r0, dq0, dq1, lane, g, ld, S - r0);
+    store_tile(Kt, r0, dk0, dk1, lane, g + H, ld, S - r0);
+    store_tile(dOt, r0, dv0, dv1, lane, g + 2 * H, ld, S - r0);
+  }
+}
+
+static size_t bwd2_lds_bytes(int nkb) {
+  const int Sp = nkb * 32, rs = (Sp <= 128) ? 256 : 512;
+  return (size_t)Sp * 128 * 3 + (size_t)2 * 32 * rs + (size_t)Sp * 8;
+}
+template <int NKB>
+static void launch_bwd2(const bf16* qkv, const uint8_t* mask, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv,
+                        float* colpart, int B, int S, int heads, int H, float scale, DropCfg d, hipStream_t st) {
+  const size_t sm = bwd2_lds_bytes(NKB);
+  (void)hipFuncSetAttribute((const void*)attn_bwd2_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  attn_bwd2_bf16_kernel<NKB><<<B * heads, (NKB <= 4 ? 4 : 8) * 64, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d);
+}
+
 static size_t fwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * 256 + (size_t)nkb * 32 * 4 + 4 * 4096; }
 static size_t bwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * (4 * 128 + 256) + (size_t)nkb * 32 * 12; }
 
@@ -516,12 +690,20 @@ extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, con
     if (dbias) return nbest_colsum(dqkv, dbias, (int64_t)B * S, 3 * H, 3 * H, NBEST_F32, accumulate, ws, ws_bytes, stream);
     return NBEST_OK;
   }
-  NB_CHECK(S <= 128, NBEST_ERR_SHAPE, "attention_bwd(bf16): S=%d > 128 is not built yet", S);
+  NB_CHECK(S <= 256, NBEST_ERR_SHAPE, "attention_bwd(bf16): S=%d > 256", S);
   const int nkb = (S + 31) / 32;
   float* colpart = dbias ? (float*)ws : nullptr;
+  // NBEST_ATTN_BWD=1 selects the first structure (everything in LDS, S <= 128) for A/B measurements
+  static const int old_structure = [] { const char* e = getenv("NBEST_ATTN_BWD"); return (e && e[0] == '1') ? 1 : 0; }();
+  if (old_structure && nkb <= 4) {
 #define F(N) case N: launch_bwd<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st); break;
-  switch (nkb) { F(1) F(2) F(3) F(4) }
+    switch (nkb) { F(1) F(2) F(3) F(4) }
 #undef F
+  } else {
+#define F(N) case N: launch_bwd2<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st); break;
+    switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
+#undef F
+  }
   NB_LAUNCH_CHECK();
   if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
   return NBEST_OK;

@@ -572,7 +572,7 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
   }
   if (rc) return rc;
   if (p.colpart) return nbest_internal_partial_rows_sum(p.colpart, p.tiles_m * 2, (int)a->N, a->colsum_out, a->colsum_accumulate, st);
-  if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1) {
+  if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1 && !(a->flags & NBEST_GEMM_DEFER_REDUCE)) {
     const int64_t MN = a->M * a->N;
     int64_t g = (MN / 4 + 255) / 256;
     if (g > 2048) g = 2048;

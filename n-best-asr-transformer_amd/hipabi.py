@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64), ("ldu", C.c_int64),
                 ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("dtype", C.c_int32),
                 ("accumulate", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64),
-                ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("pad_", C.c_int32)]
+                ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("flags", C.c_int32)]
 
 
 class LabelSpaceC(C.Structure):
@@ -142,7 +142,7 @@ def _ws(nbytes, device):
 # thin per-op wrappers (used by the kernel parity tests; training goes through encoder_forward/backward)
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=None, R=None, U=None, out=None,
-         accumulate=False, drop_p=0.0, seed=0, drop_stream=0, colsum_out=None):
+         accumulate=False, drop_p=0.0, seed=0, drop_stream=0, colsum_out=None, defer_reduce=False):
     """C[M,N] = epi(op(A) . op(B)); returns C (and U for EPI_BIAS_GELU)."""
     dt = dtype_code(A.dtype)
     dev = A.device
@@ -162,6 +162,7 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=No
     g.trans_a, g.trans_b, g.epilogue, g.dtype = int(trans_a), int(trans_b), epilogue, dt
     g.accumulate, g.drop_p, g.drop_stream, g.seed = int(accumulate), drop_p, drop_stream, seed
     g.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
+    g.flags = 1 if defer_reduce else 0
     nb = lib().nbest_gemm_ws_bytes(C.byref(g))
     ws = _ws(nb, dev)
     g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()

@@ -188,7 +188,8 @@ def _attn_ref(qkv, mask, B, S, heads):
 
 
 @pytest.mark.parametrize("dtype,S", [(torch.float32, 48), (torch.float32, 37), (torch.bfloat16, 128), (torch.bfloat16, 48),
-                                     (torch.bfloat16, 37), (torch.bfloat16, 96)])
+                                     (torch.bfloat16, 37), (torch.bfloat16, 96), (torch.bfloat16, 160), (torch.bfloat16, 256),
+                                     (torch.bfloat16, 201)])
 def test_attention_fwd_bwd(dtype, S):
     B, heads = 3, 4
     H = heads * 64
