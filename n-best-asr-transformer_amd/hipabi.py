@@ -141,6 +141,26 @@ def _ws(nbytes, device):
 # ------------------------------------------------------------------------------------------------
 # thin per-op wrappers (used by the kernel parity tests; training goes through encoder_forward/backward)
 # ------------------------------------------------------------------------------------------------
+def gemm_prepared(A, B, M, N, K, out, trans_a=False, trans_b=False, epilogue=EPI_NONE, defer_reduce=False):
+    """build the argument block + workspace ONCE and return a zero-overhead launcher (benchmark loops)"""
+    g = GemmArgs()
+    g.A, g.B, g.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = A.stride(0), B.stride(0), out.stride(0)
+    g.trans_a, g.trans_b, g.epilogue, g.dtype = int(trans_a), int(trans_b), epilogue, dtype_code(A.dtype)
+    g.flags = 1 if defer_reduce else 0
+    ws = _ws(lib().nbest_gemm_ws_bytes(C.byref(g)), A.device)
+    g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
+    fn, ref, st = lib().nbest_gemm, C.byref(g), stream_ptr()
+
+    def launch():
+        rc = fn(ref, st)
+        if rc:
+            check(rc, "gemm")
+    launch.keepalive = (g, ws, A, B, out)
+    return launch
+
+
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=None, R=None, U=None, out=None,
          accumulate=False, drop_p=0.0, seed=0, drop_stream=0, colsum_out=None, defer_reduce=False):
     """C[M,N] = epi(op(A) . op(B)); returns C (and U for EPI_BIAS_GELU)."""

@@ -35,8 +35,10 @@ def dist_info():
 def init_distributed(backend=None):
     """read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun); no-op for a single process"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if "RANK" not in os.environ:          # plain `python bench.py`: single process, no process group
         return 0, 1, 0
+    # under torchrun a process group is created even for one rank, so the RCCL path (communicator, async
+    # bucketed all-reduce, barrier) is the same code at every N and can be exercised on a 1-GPU box
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
@@ -51,8 +53,7 @@ def init_distributed(backend=None):
 
 def broadcast_parameters(model):
     """identical replicas: rank 0's master arena wins"""
-    _, world = dist_info()
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(model.arena.p, src=0)
         model.arena.refresh_compute_copy()
 
@@ -77,7 +78,7 @@ class GradReducer:
         self.pending = []
 
     def _launch(self, lo, hi):
-        if self.world > 1 and hi > lo:
+        if dist.is_available() and dist.is_initialized() and hi > lo:
             self.pending.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def layers_ready(self, l_lo, l_hi):
@@ -169,7 +170,7 @@ def train_epoch(model, data, opt, memory, epoch=0):
     """n_best_asr_bert.py:232-294 -> (mean_loss, (p, r, f), acc).  ``data`` = (asr, trans, labels) lists."""
     model.train()
     rank, world = dist_info()
-    reducer = GradReducer(model.arena) if world > 1 else None
+    reducer = GradReducer(model.arena) if (dist.is_available() and dist.is_initialized()) else None
     counts, losses = (0, 0, 0, 0, 0), []
     for raw_in, raw_trans, raw_labels in batches(data, opt.batchSize, shuffle=True, seed=getattr(opt, "random_seed", 999) + epoch):
         lo, hi = shard_bounds(len(raw_in), rank, world)
