@@ -166,13 +166,13 @@ def _prep(raw_in, raw_trans, raw_labels, opt, memory, device):
     return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=y)
 
 
-def train_epoch(model, data, opt, memory, epoch=0):
+def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
     """n_best_asr_bert.py:232-294 -> (mean_loss, (p, r, f), acc).  ``data`` = (asr, trans, labels) lists."""
     model.train()
     rank, world = dist_info()
     reducer = GradReducer(model.arena) if (dist.is_available() and dist.is_initialized()) else None
     counts, losses = (0, 0, 0, 0, 0), []
-    for raw_in, raw_trans, raw_labels in batches(data, opt.batchSize, shuffle=True, seed=getattr(opt, "random_seed", 999) + epoch):
+    for raw_in, raw_trans, raw_labels in batches(data, opt.batchSize, shuffle=shuffle, seed=getattr(opt, "random_seed", 999) + epoch):
         lo, hi = shard_bounds(len(raw_in), rank, world)
         if hi <= lo:
             continue

@@ -108,6 +108,7 @@ def main():
     ]
     for c in cases:
         run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns)
+    run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim)
 
 
 def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
@@ -236,6 +237,96 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
     fx["wordgrad_vals"] = grads["bert_encoder.embeddings.word_embeddings.weight"][used, :64].numpy()
     np.savez_compressed(os.path.join(HERE, "case_%s.npz" % c["name"]), **fx)
     print("   wrote case_%s.npz  loss=%.6f  preds[0]=%s" % (c["name"], total.item(), preds[0]))
+
+
+def run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim):
+    """Real text through the reference's own loop: utils/bert_xlnet_inputs.py, tod_asr_util.collate_fn,
+    n_best_asr_bert.train_epoch / eval_epoch (exec'd text slice :145-389), on the first lines of the shipped
+    valid split with a 2-layer bert and a local WordPiece vocabulary."""
+    print("== text case (reference train_epoch / eval_epoch)")
+    import io, contextlib, warnings
+    import utils.bert_xlnet_inputs as ref_inputs
+    import utils.dataset.tod_asr_util as ref_data
+    import utils.STC_util as ref_stc
+    import utils.fscore as ref_fscore
+    from nbest_amd import inputs as my_inputs
+    N, BS = 24, 8
+    lines = open(os.path.join(REF, "dstc2_data/processed_data/raw/valid")).read().split("\n")[:N]
+    with open(os.path.join(HERE, "valid_head.txt"), "w") as f:          # data fixture: inputs of this case
+        f.write("\n".join(lines) + "\n")
+    # local vocabulary: specials + lower-cased dataset words + a few word pieces
+    words = sorted({w.lower() for w in memory["word2idx"].keys() if w.isalpha()})
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list("abcdefghijklmnopqrstuvwxyz") + list("?,.'") + \
+            ["##s", "##ing", "##ed", "##er", "##ly", "##n", "##t", "##e", "##a", "##y"] + [w for w in words if len(w) > 1]
+    vocab = list(dict.fromkeys(vocab))
+    with open(os.path.join(HERE, "text_vocab.json"), "w") as f:
+        json.dump(vocab, f)
+    tok = my_inputs.WordPieceTokenizer(vocab)
+    import transformers
+    hf_tok = transformers.BertTokenizer(vocab={w: i for i, w in enumerate(vocab)}, do_lower_case=True)
+    data = ref_data.read_wcn_data(os.path.join(HERE, "valid_head.txt"))
+    for seq in list(data[0]) + list(data[1]):                           # my tokenizer == HF BertTokenizer on every word
+        for w in seq:
+            if w not in ("[CLS]", "[SYS]", "[USR]", "[SEP]"):
+                assert tok.tokenize(w) == hf_tok.tokenize(w), (w, tok.tokenize(w), hf_tok.tokenize(w))
+    fx = {}
+    for mode in ("bert", "bert_nosys"):
+        opt_i = types.SimpleNamespace(pre_trained_model="bert", tod_pre_trained_model=None, without_system_act=(mode == "bert_nosys"))
+        ids_r, seg_r, lens_r = ref_inputs.prepare_inputs_for_roberta(list(data[0][:BS]), tok, opt_i, "cpu")
+        ids_m, seg_m, lens_m = my_inputs.prepare_inputs_for_roberta(list(data[0][:BS]), tok, opt_i, "cpu")
+        assert torch.equal(ids_r, ids_m) and lens_r == lens_m and ((seg_r is None and seg_m is None) or torch.equal(seg_r, seg_m))
+        fx["ids_" + mode] = ids_r.numpy()
+        if seg_r is not None:
+            fx["seg_" + mode] = seg_r.numpy()
+        tr, _, _ = ref_inputs.prepare_inputs_for_roberta(list(data[1][:BS]), tok, opt_i, "cpu")
+        fx["tids_" + mode] = tr.numpy()
+    print("   input builder == reference on %d utterances (bert, --without_system_act); tokenizer == HF BertTokenizer" % BS)
+
+    # the reference loop
+    src = open(os.path.join(REF, "n_best_asr_bert.py")).read()
+    body = src[src.index("def cal_ce_loss"):src.index("def train(model")]
+    ns = dict(np=np, torch=torch, nn=nn, update_f1=ref_fscore.update_f1, compute_f1=ref_fscore.compute_f1,
+              prepare_inputs_for_roberta=ref_inputs.prepare_inputs_for_roberta, convert_labels=ref_stc.convert_labels,
+              onehot_to_scalar=ref_stc.onehot_to_scalar, EpochInfoCollector=ref_data.EpochInfoCollector)
+    exec(compile(body, "n_best_asr_bert.py[145:389]", "exec"), ns)
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=len(vocab), hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = synth.model_state(cfg, labels, seed=21)
+    enc = hf_encoder(cfg)
+    opt = types.SimpleNamespace(pretrained_model=enc, dropout=0.0, device=torch.device("cpu"), score_util="pp", sent_repr="bin_sa_cls",
+                                cls_type="stc", top2bottom_dict=memory["top2bottom_dict"], label_vocab_size=labels.n_bottom,
+                                pre_trained_model="bert", tod_pre_trained_model=None, without_system_act=False, add_l2_loss=True,
+                                add_segment_ids=True, tokenizer=tok, n_accum_steps=1, optim_choice="bertadam", max_norm=5.0,
+                                ontology=None, testing=False, class_loss_function=nn.BCELoss(reduction="sum"),
+                                ce_loss_function=nn.NLLLoss(reduction="sum"), mse_loss_function=nn.MSELoss())
+    model = ref_model.make_model(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    groups = [dict(params=p, weight_decay=0.0 if any(nd in n for nd in no_decay) else 0.01,
+                   lr=3e-5 if "bert_encoder" in n else 5e-4) for n, p in named]
+    t_total = 30
+    opt.optimizer = ref_optim.BertAdam(groups, lr=5e-4, warmup=0.1, t_total=t_total)
+    loader = ref_data.prepare_wcn_dataloader(data, memory, BS, None, opt.device, shuffle_flag=False)
+    before = {n: p.detach().clone() for n, p in named}
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr_loss, (trp, trr, trf), tr_acc = ns["train_epoch"](model, loader, opt, memory)
+        fp, efp = io.StringIO(), io.StringIO()
+        ev_loss, (evp, evr, evf), ev_acc, eic = ns["eval_epoch"](model, loader, opt, memory, fp, efp)
+    print("   reference train_epoch: loss %.4f p/r/f %.2f/%.2f/%.2f acc %.2f ; eval_epoch: loss %.4f f %.2f acc %.2f" % (
+        tr_loss, trp, trr, trf, tr_acc, ev_loss, evf, ev_acc))
+    fx.update(train=np.array([tr_loss, trp, trr, trf, tr_acc]), evalm=np.array([ev_loss, evp, evr, evf, ev_acc]),
+              t_total=np.array(t_total), n_lines=np.array(N), batch=np.array(BS), seed=np.array(21))
+    for n in ("bert_encoder.encoder.layer.1.output.dense.weight", "bert_encoder.embeddings.word_embeddings.weight",
+              "clf.top_linear_layer.weight", "clf.linear_layers.lin_2.bias"):
+        d = dict(named)[n].detach() - before[n]
+        fx["delta/" + n] = d.reshape(-1, d.shape[-1])[:8, :64].numpy() if d.dim() > 1 else d[:64].numpy()
+    fx["eval_lines"] = np.array(fp.getvalue())
+    labels_mh = ref_data.collate_fn(list(zip(data[0][:BS], data[1][:BS], data[2][:BS])), memory, None, "cpu")[0]
+    fx["labels_multihot"] = labels_mh.numpy()
+    fx["label2idx"] = np.array(json.dumps({k: int(v) for k, v in memory["label2idx"].items()}))
+    np.savez_compressed(os.path.join(HERE, "case_text.npz"), **fx)
+    print("   wrote case_text.npz, valid_head.txt, text_vocab.json")
 
 
 if __name__ == "__main__":

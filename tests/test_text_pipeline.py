@@ -1,0 +1,77 @@
+"""Real-text parity with the reference's own loop (fixture tests/golden/case_text.npz, produced by running
+/root/reference utils/bert_xlnet_inputs.py, utils/dataset/tod_asr_util.py and n_best_asr_bert.py
+train_epoch / eval_epoch on the first 24 lines of the shipped valid split)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+import nbest_amd  # noqa: F401
+from nbest_amd import config as ncfg, inputs, synth, trainer
+
+
+def _load():
+    z = np.load(os.path.join(GOLDEN, "case_text.npz"))
+    vocab = json.load(open(os.path.join(GOLDEN, "text_vocab.json")))
+    data = trainer.read_wcn_data(os.path.join(GOLDEN, "valid_head.txt"))
+    return z, vocab, data
+
+
+def test_input_builder_and_labels_match_reference():
+    z, vocab, data = _load()
+    tok = inputs.WordPieceTokenizer(vocab)
+    B = int(z["batch"])
+    for mode in ("bert", "bert_nosys"):
+        opt = types.SimpleNamespace(pre_trained_model="bert", tod_pre_trained_model=None, without_system_act=(mode == "bert_nosys"))
+        ids, seg, lens = inputs.prepare_inputs_for_roberta(data[0][:B], tok, opt, "cpu")
+        assert np.array_equal(ids.numpy(), z["ids_" + mode])
+        if mode == "bert":
+            assert np.array_equal(seg.numpy(), z["seg_" + mode])
+        else:
+            assert seg is None
+        tids, _, _ = inputs.prepare_inputs_for_roberta(data[1][:B], tok, opt, "cpu")
+        assert np.array_equal(tids.numpy(), z["tids_" + mode])
+        assert lens == [int((r != 0).sum()) for r in z["ids_" + mode]]
+    label2idx = json.loads(str(z["label2idx"]))
+    y = trainer.labels_to_multihot(data[2][:B], label2idx, "cpu")
+    assert np.array_equal(y.numpy(), z["labels_multihot"])              # collate_fn labels (tod_asr_util.py:114-123)
+    assert len(data[0]) == int(z["n_lines"]) and data[0][0][:2] == ["[CLS]", "[SYS]"]
+
+
+@pytest.mark.gpu
+def test_train_and_eval_epoch_match_reference(labels):
+    """fp32 path: one epoch (3 steps, BertAdam, --add_l2_loss, --add_segment_ids) then an eval epoch over the same
+    utterances reproduce the reference loop's loss / P / R / F / Acc, its parameter updates and its output lines."""
+    import io
+    from nbest_amd.model import NBestSTCModel
+    from nbest_amd.optim import HipBertAdam
+    z, vocab, data = _load()
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=len(vocab), hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.float32, dropout=0.0)
+    m.load_reference_state(synth.model_state(cfg, labels, seed=int(z["seed"])))
+    named = dict(m.named_parameters())
+    before = {k[6:]: named[k[6:]].detach().clone() for k in z.files if k.startswith("delta/")}
+    label2idx = json.loads(str(z["label2idx"]))
+    memory = dict(label2idx=label2idx, idx2label=labels.idx2label)
+    opt = types.SimpleNamespace(batchSize=int(z["batch"]), tokenizer=inputs.WordPieceTokenizer(vocab), pre_trained_model="bert",
+                                tod_pre_trained_model=None, without_system_act=False, add_l2_loss=True, add_segment_ids=True)
+    opt.optimizer = HipBertAdam(m, lr=5e-4, bert_lr=3e-5, warmup=0.1, t_total=int(z["t_total"]))
+    loss, (p, r, f), acc = trainer.train_epoch(m, data, opt, memory, shuffle=False)
+    ref = z["train"]
+    assert abs(loss - ref[0]) <= 1e-4 * abs(ref[0]), (loss, ref[0])
+    assert (p, r, f, acc) == pytest.approx(tuple(ref[1:]), abs=1e-9)      # identical predictions -> identical counts
+    for k, b0 in before.items():
+        d = (named[k].detach() - b0).cpu()
+        got = d.reshape(-1, d.shape[-1])[:8, :64] if d.dim() > 1 else d[:64]
+        assert np.abs(got.numpy() - z["delta/" + k]).max() <= 2e-6, k
+    fp, efp = io.StringIO(), io.StringIO()
+    eloss, (ep, er, ef), eacc, cases = trainer.eval_epoch(m, data, opt, memory, fp, efp)
+    eref = z["evalm"]
+    assert abs(eloss - eref[0]) <= 2e-4 * abs(eref[0]), (eloss, eref[0])
+    assert (ep, er, ef, eacc) == pytest.approx(tuple(eref[1:]), abs=1e-9)
+    assert fp.getvalue() == str(z["eval_lines"])                          # raw <=> pred <=> gold lines, byte for byte
