@@ -218,6 +218,17 @@ int nbest_bertadam_chunk(void);
 int nbest_bertadam_step(float* p, float* g, float* m, float* v, void* p_lowp, const nbest_tensor_desc* descs,
                         int n_tensors, int n_blocks, float lr_mult, float b1, float b2, float eps,
                         float max_grad_norm, void* ws, size_t ws_bytes, nbest_stream_t stream);
+/* Transposed bf16 copy of the weight matrices (same element offsets in `dst` as in `src`): matrix t is
+ * [rows][cols] in src and [cols][rows] in dst.  The backward's dgrad GEMMs read this copy so that both of
+ * their operands are k-contiguous (no transposed LDS reads).  descs: DEVICE array ordered by tile_start,
+ * tile_start[t] = sum_{u<t} ceil(rows/64)*ceil(cols/64); n_tiles = that sum over all matrices.          */
+typedef struct nbest_matrix_desc {
+  int64_t offset;
+  int32_t rows, cols;
+  int32_t tile_start, pad;
+} nbest_matrix_desc;
+int nbest_transpose_weights(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_tiles,
+                            nbest_stream_t stream);
 /* fp32 -> bf16 copy of an arena (initial compute copy / after loading a checkpoint) */
 int nbest_cast_f32_to_bf16(const float* src, void* dst, int64_t n, nbest_stream_t stream);
 
@@ -256,7 +267,9 @@ int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wts, const fl
  * with_embeddings != 0 also runs the embedding backward (needs layer_begin == 0).  Calling it in
  * chunks (L..k, k..0+embeddings) lets the host start the gradient all-reduce of finished layers
  * while the remaining backward runs.                                                                */
-int nbest_encoder_backward(const nbest_encoder_desc* d, const void* wts, const float* prm, float* grad,
+/* wts_t: optional arena holding the TRANSPOSED weight matrices (nbest_transpose_weights); NULL -> the dgrad
+ * GEMMs read `wts` with transposed LDS reads.                                                            */
+int nbest_encoder_backward(const nbest_encoder_desc* d, const void* wts, const void* wts_t, const float* prm, float* grad,
                            const int64_t* ids, const int64_t* seg, const int64_t* pos, const uint8_t* key_mask,
                            void* act, size_t act_bytes, void* dhidden, void* ws, size_t ws_bytes, int accumulate,
                            int layer_begin, int layer_end, int with_embeddings, nbest_stream_t stream);

@@ -104,6 +104,22 @@ class ParamArena:
         self.m = None
         self.v = None
         self.w16 = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) if compute_dtype == torch.bfloat16 else None
+        # transposed bf16 copy of the per-layer weight matrices (same offsets): the dgrad GEMMs read it so both of
+        # their operands are k-contiguous.  Only allocated on a GPU (the kernel that fills it is HIP).
+        self.w16t = None
+        self._tdescs = None
+        if self.w16 is not None and self.device.type == "cuda":
+            self.w16t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+            H, F = cfg.hidden_size, cfg.intermediate_size
+            mats = []
+            for o in self.layer_offsets:
+                mats += [(o.wqkv, 3 * H, H), (o.wo, H, H), (o.w1, F, H), (o.w2, H, F)]
+            arr = (hb.MatrixDesc * len(mats))()
+            t = 0
+            for i, (off, r, c) in enumerate(mats):
+                arr[i].offset, arr[i].rows, arr[i].cols, arr[i].tile_start = off, r, c, t
+                t += ((r + 63) // 64) * ((c + 63) // 64)
+            self._tdescs = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(mats), t)
         self._descs = None
 
     # ---- views ---------------------------------------------------------------------------------
@@ -127,6 +143,13 @@ class ParamArena:
     def refresh_compute_copy(self):
         if self.w16 is not None:
             hb.cast_bf16(self.p, self.w16)
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        if self.w16t is not None:
+            d, n, t = self._tdescs
+            hb.check(hb.lib().nbest_transpose_weights(hb.ptr(self.w16), hb.ptr(self.w16t), hb.ptr(d), n, t, hb.stream_ptr()),
+                     "transpose_weights")
 
     def load_state(self, sd, strict=True):
         """copy a reference-keyed state dict (numpy arrays or tensors) into the master arena"""

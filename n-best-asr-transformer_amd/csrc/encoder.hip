@@ -183,7 +183,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
   return NBEST_OK;
 }
 
-extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* wts, const float* prm, float* grad,
+extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* wts, const void* wts_t, const float* prm, float* grad,
                                       const int64_t* ids, const int64_t* seg, const int64_t* pos, const uint8_t* key_mask,
                                       void* act, size_t act_bytes, void* dhidden, void* ws, size_t ws_bytes, int accumulate,
                                       int layer_begin, int layer_end, int with_embeddings, nbest_stream_t stream) {
@@ -196,6 +196,10 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   NB_CHECK(ws_bytes >= w.total, NBEST_ERR_WORKSPACE, "encoder_backward: workspace too small (%zu < %zu)", ws_bytes, w.total);
   hipStream_t st = (hipStream_t)stream;
   const Ptrs P{(const char*)wts, prm, a.esz};
+  // dgrad operand: with a transposed weight arena both GEMM operands are k-contiguous (B given as [N][K])
+  const bool wt = (wts_t != nullptr);
+  const Ptrs PT{(const char*)(wt ? wts_t : wts), prm, a.esz};
+  const int tbd = wt ? 0 : 1;
   char* A = (char*)act;
   char* W = (char*)ws;
   const int64_t M = a.M;
@@ -223,26 +227,26 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
                             d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream));
     // FFN-down: dgrad fused with GELU' -> dU ; wgrad
     // (the FFN-up bias gradient = column sums of dU is fused into this epilogue)
-    RUN(gemm(dt, dRd, P.W(o.w2), dBig, M, F, H, H, F, F, 0, 1, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red, w.red_bytes, accumulate,
+    RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red, w.red_bytes, accumulate,
              0.f, 0, 0, st, G(o.b1)));
     RUN(gemm(dt, dRd, hact, G(o.w2), H, F, M, H, F, F, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
     // FFN-up: dgrad + residual gradient ; wgrad
-    RUN(gemm(dt, dBig, P.W(o.w1), dB1, M, H, F, F, H, H, 0, 1, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    RUN(gemm(dt, dBig, PT.W(o.w1), dB1, M, H, F, F, wt ? F : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
     // LN1 backward
     RUN(nbest_layernorm_bwd(dB1, r1, st1, P.P(o.ln1_g), dR, hdrop ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt, accumulate,
                             d->hidden_drop, d->seed, s0 + 1, red, w.red_bytes, stream));
     // attention output projection: dgrad ; wgrad
-    RUN(gemm(dt, dRd, P.W(o.wo), dctx, M, H, H, H, H, H, 0, 1, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
     // attention backward -> dqkv ; QKV bias gradient
     RUN(nbest_attention_bwd(qkv, key_mask, ctx, dctx, lse, dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64, dt,
                             d->attn_drop, d->seed, s0 + 0, stream));
     // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
-    RUN(gemm(dt, dqkv, P.W(o.wqkv), dA, M, H, 3 * H, 3 * H, H, H, 0, 1, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
              w.slab_bytes, accumulate, 0.f, 0, 0, st));
   }

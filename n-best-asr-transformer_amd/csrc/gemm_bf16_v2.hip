@@ -26,6 +26,10 @@
 namespace {
 
 constexpr int BK = 32;
+#ifndef NBEST_DIAG
+#define NBEST_DIAG 0
+#endif
+constexpr int DIAG = NBEST_DIAG;   // timing-only ablation builds of the ping-pong loop: 1 no in-loop DMA, 2 no fragment reads, 4 no MFMA
 
 struct GemmP2 {
   const bf16* A; const bf16* B; void* C; const float* bias; const bf16* R; bf16* U; float* slab; float* colpart;
@@ -173,9 +177,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     asm volatile("" ::: "memory");
     if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
     int buf = 0;
+    bf16x8 af[TMt], bfr[TNt];
     for (int kt = 0; kt < nk; ++kt) {
       // ---------------- LOAD slot ----------------
-      if (kt + STAGES - 1 < nk) {
+      if (kt + STAGES - 1 < nk && !(DIAG & 1)) {
         int nb = buf + STAGES - 1;
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
@@ -183,11 +188,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         stage_tile2<TB, BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
       }
       const char* cur = lds + buf * STAGE;
-      bf16x8 af[TMt], bfr[TNt];
+      if ((DIAG & 2) == 0 || kt == 0) {
 #pragma unroll
-      for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<TB, BN>(cur + A_BYTES, wn * WTN + j * 16, lane);
+        for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<TB, BN>(cur + A_BYTES, wn * WTN + j * 16, lane);
 #pragma unroll
-      for (int i = 0; i < TMt; ++i) af[i] = read_frag2<TA, BM>(cur, wm * WTM + i * 16, lane);
+        for (int i = 0; i < TMt; ++i) af[i] = read_frag2<TA, BM>(cur, wm * WTM + i * 16, lane);
+      }
       {
         // retire this wave's share of stage kt+1 (read by group 0 two slots from now)
         const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1;   // stages kt+1.. outstanding
@@ -200,10 +206,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- MFMA slot ----------------
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (!(DIAG & 4)) {
 #pragma unroll
-      for (int i = 0; i < TMt; ++i)
+        for (int i = 0; i < TMt; ++i)
 #pragma unroll
-        for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TMt; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) asm volatile("" :: "v"(bfr[j]));
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();

@@ -111,7 +111,44 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
   }
 }
 
+// bf16 [rows][cols] -> [cols][rows] for a table of matrices living at the same element offsets in two
+// arenas (the k-contiguous weight copy the dgrad GEMMs read).  One launch: block -> (matrix, 64x64 tile).
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                              const nbest_matrix_desc* __restrict__ descs, int n) {
+  __shared__ bf16 tile[64][66];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const nbest_matrix_desc d = descs[lo];
+  const int t = blockIdx.x - d.tile_start, tc = (d.cols + 63) / 64;
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const bf16* s = src + d.offset;
+  bf16* o = dst + d.offset;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (r < d.rows && c < d.cols) ? s[(int64_t)r * d.cols + c] : (bf16)0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < d.cols && r < d.rows) o[(int64_t)c * d.rows + r] = tile[tx][ty + 4 * i];
+  }
+}
+
 }  // namespace
+
+extern "C" int nbest_transpose_weights(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_tiles,
+                                       nbest_stream_t stream) {
+  NB_CHECK(src && dst && descs && n_matrices > 0 && n_tiles > 0, NBEST_ERR_ARG, "transpose_weights: bad arguments");
+  transpose_multi_kernel<<<n_tiles, 256, 0, (hipStream_t)stream>>>((const bf16*)src, (bf16*)dst, descs, n_matrices);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
 
 extern "C" int nbest_bertadam_chunk(void) { return kChunk; }
 

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnbest_hip.so")
+LIB_PATH = os.environ.get("NBEST_LIB") or os.path.join(_HERE, "csrc", "libnbest_hip.so")   # NBEST_LIB: diagnostic builds only
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_DGELU, EPI_RES, EPI_F32_SPLITK = range(7)
@@ -20,7 +20,7 @@ EXPORTS = [
     "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step",
-    "nbest_cast_f32_to_bf16", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
+    "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
     "nbest_encoder_backward",
 ]
 
@@ -43,6 +43,10 @@ class LabelSpaceC(C.Structure):
 class TensorDesc(C.Structure):
     _fields_ = [("offset", C.c_int64), ("numel", C.c_int64), ("lr", C.c_float), ("wd", C.c_float),
                 ("active", C.c_int32), ("block_start", C.c_int32)]
+
+
+class MatrixDesc(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("tile_start", C.c_int32), ("pad", C.c_int32)]
 
 
 class LayerOffsets(C.Structure):
@@ -101,7 +105,8 @@ def lib():
         L.nbest_bertadam_step.argtypes = [vp] * 6 + [i32, i32, f32, f32, f32, f32, f32, vp, sz, vp]
         L.nbest_cast_f32_to_bf16.argtypes = [vp, vp, i64, vp]
         L.nbest_encoder_forward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 7 + [sz, vp, sz, C.POINTER(C.c_void_p), vp]
-        L.nbest_encoder_backward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 8 + [sz, vp, vp, sz, i32, i32, i32, i32, vp]
+        L.nbest_encoder_backward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 9 + [sz, vp, vp, sz, i32, i32, i32, i32, vp]
+        L.nbest_transpose_weights.argtypes = [vp, vp, vp, i32, i32, vp]
         L.nbest_last_error.argtypes = [C.c_char_p, sz]
         _lib = L
     return _lib

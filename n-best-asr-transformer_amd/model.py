@@ -154,7 +154,8 @@ class NBestSTCModel(nn.Module):
         L = cfg.num_hidden_layers
         bounds = chunks or [(0, L)]
         for (lo, hi) in sorted(bounds, reverse=True):
-            hb.check(hb.lib().nbest_encoder_backward(C.byref(ps.desc), hb.ptr(self.arena.weights), hb.ptr(self.arena.p),
+            hb.check(hb.lib().nbest_encoder_backward(C.byref(ps.desc), hb.ptr(self.arena.weights), hb.ptr(self.arena.w16t),
+                                                     hb.ptr(self.arena.p),
                                                      hb.ptr(self.arena.g), hb.ptr(ids), hb.ptr(seg), hb.ptr(pos), hb.ptr(mask),
                                                      hb.ptr(ps.act), ps.act.numel(), hb.ptr(dh), hb.ptr(self._ws), self._ws_bytes,
                                                      int(accumulate), lo, hi, int(lo == 0), hb.stream_ptr()), "encoder_backward")

@@ -47,6 +47,7 @@ class HipBertAdam:
                                               hb.ptr(self.descs), self.n_tensors, self.n_blocks, self.get_lr_mult(),
                                               self.b1, self.b2, self.e, self.max_grad_norm, hb.ptr(self.ws),
                                               self.ws.numel(), hb.stream_ptr()), "bertadam_step")
+        a.refresh_transposed()
         self.step_count += 1
 
     def state_dict(self):
