@@ -9,7 +9,7 @@ holds the full arenas, the minibatch is sharded across ranks.  The reference's B
 reductions (n_best_asr_bert.py:572-574), so gradients are all-reduced with SUM (not mean) and the MSE
 term (a mean over B x H) is pre-scaled by 1/world.  The backward runs in layer chunks; as soon as a
 chunk's gradients are complete their slice of the flat gradient arena is all-reduced asynchronously
-(RCCL on its own stream over xGMI) while the remaining backward - ending with the embedding backward -
+(RCCL on its own stream over xGMI; 6 chunks of 2 layers for bert-base) while the remaining backward - ending with the embedding backward -
 keeps the compute stream busy.  Per-tensor clipping + BertAdam run after the last reduce.
 """
 import os
@@ -68,7 +68,7 @@ def shard_bounds(n, rank, world):
 class GradReducer:
     """bucketed asynchronous SUM all-reduce of slices of the flat gradient arena"""
 
-    def __init__(self, arena, n_chunks=3):
+    def __init__(self, arena, n_chunks=6):
         self.arena = arena
         self.rank, self.world = dist_info()
         L = len(arena.layer_range)

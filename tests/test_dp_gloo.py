@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     torch.manual_seed(rank)
     a.g.copy_(torch.randn(a.total))
     local = a.g.clone()
-    red = trainer.GradReducer(a, n_chunks=3)
+    red = trainer.GradReducer(a, n_chunks=3)      # explicit: 4 layers -> (0,1) (1,3) (3,4)
     assert red.chunks == [(0, 1), (1, 3), (3, 4)]
     for lo, hi in sorted(red.chunks, reverse=True):              # the order the backward produces them
         red.layers_ready(lo, hi)
