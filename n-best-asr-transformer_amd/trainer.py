@@ -112,7 +112,26 @@ def train_step(model, optimizer, batch, add_l2_loss=False, add_segment_ids=True,
 # ------------------------------------------------------------------------------------------------
 # data: "ASR \t<=>\t TRANSCRIPT \t<=>\t label1;label2" lines
 # ------------------------------------------------------------------------------------------------
-def read_wcn_data(fn):
+def coverage_sample(labels, coverage, seed=42):
+    """Row order of the --coverage stratified subsample, /root/reference/utils/dataset/tod_asr_util.py:12-39:
+    the first utterance of every distinct label set (file order), then
+    rem = round(|coverage * N - n_unique|) of the remaining utterances drawn without replacement by
+    pandas' DataFrame.sample(n=rem, random_state=42) = numpy RandomState(42).choice(len(rest), rem, False)."""
+    seen, uniq = set(), []
+    for i, l in enumerate(labels):
+        t = tuple(l)
+        if t not in seen:
+            seen.add(t)
+            uniq.append(i)
+    uset = set(uniq)
+    rest = [i for i in range(len(labels)) if i not in uset]
+    rem = int(np.round(abs(float(coverage) * len(labels) - len(uniq))))
+    pick = np.random.RandomState(seed).choice(len(rest), size=rem, replace=False)
+    return uniq + [rest[int(j)] for j in pick]
+
+
+def read_wcn_data(fn, coverage=None):
+    """``ASR \\t<=>\\t TRANSCRIPT \\t<=>\\t label1;label2`` lines (tod_asr_util.py:43-71); coverage: see coverage_sample"""
     asr, trans, labels = [], [], []
     with open(fn) as fp:
         for line in fp:
@@ -120,6 +139,9 @@ def read_wcn_data(fn):
             asr.append(a.strip().split(" "))
             trans.append(t.strip().split(" "))
             labels.append(lbl.strip().split(";") if lbl else [])
+    if coverage:
+        order = coverage_sample(labels, coverage)
+        asr, trans, labels = [asr[i] for i in order], [trans[i] for i in order], [labels[i] for i in order]
     return asr, trans, labels
 
 

@@ -109,6 +109,7 @@ def main():
     for c in cases:
         run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns)
     run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim)
+    run_coverage_case()
 
 
 def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
@@ -327,6 +328,36 @@ def run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim):
     fx["label2idx"] = np.array(json.dumps({k: int(v) for k, v in memory["label2idx"].items()}))
     np.savez_compressed(os.path.join(HERE, "case_text.npz"), **fx)
     print("   wrote case_text.npz, valid_head.txt, text_vocab.json")
+
+
+def run_coverage_case():
+    """--coverage stratified sampler of the reference (tod_asr_util.py:12-71) on the first 200 valid lines and on
+    the whole valid split (digest only)."""
+    import hashlib, io, contextlib
+    import utils.dataset.tod_asr_util as ref_data
+    from nbest_amd import trainer
+    src = os.path.join(REF, "dstc2_data/processed_data/raw/valid")
+    lines = open(src).read().split("\n")[:200]
+    small = os.path.join(HERE, "valid_200.txt")
+    with open(small, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+    def digest(a, t, l):
+        h = hashlib.sha1()
+        for x, y, z in zip(a, t, l):
+            h.update((" ".join(x) + "|" + " ".join(y) + "|" + ";".join(z) + "\n").encode())
+        return h.hexdigest()
+    out = {}
+    for name, fn, covs in (("valid_200", small, (0.3, 0.5, 1.0)), ("valid_full", src, (0.05, 0.2, 1.0))):
+        for cov in covs:
+            with contextlib.redirect_stdout(io.StringIO()):
+                a, t, l = ref_data.read_wcn_data(fn, cov)
+            ma, mt, ml = trainer.read_wcn_data(fn, cov)
+            assert len(a) == len(ma) and digest(a, t, l) == digest(ma, mt, ml), (name, cov)
+            out["%s@%s" % (name, cov)] = dict(n=len(a), sha1=digest(a, t, l))
+            print("   coverage %-10s %.2f -> %d rows  (nbest_amd.trainer.read_wcn_data identical)" % (name, cov, len(a)))
+    with open(os.path.join(HERE, "coverage.json"), "w") as f:
+        json.dump(out, f, indent=1)
 
 
 if __name__ == "__main__":

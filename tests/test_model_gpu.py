@@ -140,3 +140,67 @@ def test_reference_signature_forward_eval(labels):
     assert bottoms["lin_2"].shape == (meta["B"], 75)
     keys = set(m.state_dict().keys())
     assert "bert_encoder.encoder.layer.0.attention.self.query.weight" in keys and "clf.linear_layers.lin_25.bias" in keys
+
+
+def _oracle_for(cfg, sd, labels):
+    from oracle.encoder import EncoderConfig
+    from oracle.model import OracleModel
+    ocfg = EncoderConfig(**{k: v for k, v in cfg.to_dict().items() if k in EncoderConfig.__dataclass_fields__})
+    om = OracleModel(ocfg, labels.top2bottom, labels.n_bottom, 0.0)
+    om.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    om.train()
+    return om
+
+
+@pytest.mark.parametrize("B,S,St", [(1, 5, 3), (2, 33, 9), (5, 96, 20), (2, 200, 40), (1, 256, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_edge_shapes_match_oracle(B, S, St, dtype, labels):
+    """ragged / tiny / maximum-length batches (S = 5 .. 256, single utterance) against the oracle on the same inputs"""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    from oracle import stc
+    cfg = ncfg.bert_base(num_hidden_layers=1, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = synth.model_state(cfg, labels, seed=31)
+    n_best = 2 if S < 16 else 5
+    batch = synth.nbest_batch(cfg, labels, B, S, n_best=n_best, seed=S, ragged=True, trans_len=St)
+    om = _oracle_for(cfg, sd, labels)
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    top, bottoms, final, asr, tr = om(t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"])
+    rec, total, parts = stc.total_loss(top, bottoms, final, t["labels"], labels.top2bottom, stc.bottom2top_matrix(labels.top2bottom),
+                                       asr, tr, True)
+    total.backward()
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0)
+    m.load_reference_state(sd)
+    m.train()
+    b = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+    out = m.forward_backward(b["ids"], b["labels"], seg_ids=b["seg"], trans_input_ids=b["tids"], trans_seg_ids=b["tseg"], add_l2_loss=True)
+    f32 = dtype == torch.float32
+    tag = "edge B=%d S=%d %s " % (B, S, "f32" if f32 else "bf16")
+    _cmp(tag + "top", out["top"], top.detach(), atol=1e-4 if f32 else 1e-2)
+    _cmp(tag + "final", out["final"], final.detach(), atol=1e-4 if f32 else 1e-2)
+    assert abs(out["loss_parts"].sum().item() - total.item()) <= (1e-4 if f32 else 1e-2) * abs(total.item())
+    named = dict(m.named_parameters())
+    for n, p in om.named_parameters():
+        if p.grad is None or n.endswith("attention.self.key.bias"):
+            continue
+        ref = p.grad.norm().item()
+        got = named[n].grad.norm().item()
+        # bf16 with one or two utterances: a single sample's softmax-head gradient moves ~10 % under bf16 hidden states
+        rel = 2e-3 if f32 else (5e-2 if B > 2 else 2e-1)
+        assert abs(got - ref) <= rel * max(ref, 1e-6) + (1e-6 if f32 else 1e-3), (n, got, ref)
+    if f32:
+        dec = stc.decode_indices(top.detach(), {k: v.detach() for k, v in bottoms.items()}, labels.top2bottom, labels.idx2label)
+        assert torch.equal(m.decode(out["top"], out["bott"]).cpu().long(), dec)
+
+
+def test_too_long_sequence_fails_loudly(labels):
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    cfg = ncfg.bert_base(num_hidden_layers=1, vocab_size=3000)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.bfloat16)
+    m.load_reference_state(synth.model_state(cfg, labels, seed=1))
+    ids = torch.randint(5, 2000, (1, 300), device="cuda")
+    with pytest.raises(RuntimeError, match="S=300"):
+        m.forward_backward(ids, torch.zeros(1, labels.n_bottom, device="cuda"))

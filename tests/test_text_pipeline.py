@@ -75,3 +75,21 @@ def test_train_and_eval_epoch_match_reference(labels):
     assert abs(eloss - eref[0]) <= 2e-4 * abs(eref[0]), (eloss, eref[0])
     assert (ep, er, ef, eacc) == pytest.approx(tuple(eref[1:]), abs=1e-9)
     assert fp.getvalue() == str(z["eval_lines"])                          # raw <=> pred <=> gold lines, byte for byte
+
+
+def test_coverage_sampler_matches_reference():
+    """--coverage: same rows in the same order as the reference's pandas-based stratified sampler
+    (digests produced by tests/golden/make_golden.py from /root/reference/utils/dataset/tod_asr_util.py)."""
+    import hashlib
+    gold = json.load(open(os.path.join(GOLDEN, "coverage.json")))
+    fn = os.path.join(GOLDEN, "valid_200.txt")
+    for cov in (0.3, 0.5, 1.0):
+        a, t, l = trainer.read_wcn_data(fn, cov)
+        h = hashlib.sha1()
+        for x, y, z in zip(a, t, l):
+            h.update((" ".join(x) + "|" + " ".join(y) + "|" + ";".join(z) + "\n").encode())
+        g = gold["valid_200@%s" % cov]
+        assert len(a) == g["n"] and h.hexdigest() == g["sha1"], cov
+    assert gold["valid_full@0.05"]["n"] == 522           # SURVEY quirk Q10
+    full = trainer.read_wcn_data(fn)
+    assert len(full[0]) == 200
