@@ -26,7 +26,7 @@ from datetime import timedelta
 import numpy as np
 import torch
 
-from . import config as ncfg, synth, trainer
+from . import config as ncfg, observe, synth, trainer
 from .inputs import WordPieceTokenizer
 from .model import NBestSTCModel
 from .optim import HipBertAdam
@@ -80,10 +80,16 @@ def parse_arguments(argv=None):
     g.add_argument("--add_l2_loss", action="store_true")
     g.add_argument("--without_system_act", action="store_true")
     g.add_argument("--add_segment_ids", action="store_true")
+    g.add_argument("--ontology_path", default=None, help="ontology JSON: evaluation keeps informative act-slot-value labels only")
     g = ap.add_argument_group("additive flags of this build")
     g.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     g.add_argument("--n_best", type=int, default=None, help="keep only the first n hypotheses of every utterance")
     g.add_argument("--init_checkpoint", default=None, help="state dict (reference keys) to start from")
+    g.add_argument("--pretrained_path", default=None,
+                   help="LOCAL HF-format encoder checkpoint (directory or model.safetensors / pytorch_model.bin); its vocab.txt is "
+                        "used when --vocab is not given.  Stands in for from_pretrained(name), which needs the network")
+    g.add_argument("--stop_after_epoch", type=int, default=None, help="leave after this epoch (preemption drills; use with --resume)")
+    g.add_argument("--resume", action="store_true", help="continue from <exp_dir>/last.pt (model + BertAdam state + epoch)")
     g.add_argument("--vocab", default=None, help="WordPiece vocabulary: vocab.txt (one token per line) or a JSON list")
     g.add_argument("--label_space", default=None, help="JSON with top2bottom / idx2label instead of memory.pt")
     g.add_argument("--encoder_layers", type=int, default=None, help="override the number of encoder layers (smoke runs)")
@@ -92,6 +98,7 @@ def parse_arguments(argv=None):
         ap.error("only --optim_choice bertadam is built (the shipped script's choice)")
     if opt.deviceId < 0:
         ap.error("--deviceId -1 (CPU) is not available: the path is HIP-only")
+    opt.ontology = None if opt.ontology_path is None else json.load(open(opt.ontology_path))       # n_best_asr_bert.py:138-140
     return opt
 
 
@@ -118,6 +125,8 @@ def load_memory(opt):
 
 
 def load_tokenizer(opt, memory):
+    if not opt.vocab and opt.pretrained_path and os.path.exists(os.path.join(opt.pretrained_path, "vocab.txt")):
+        opt.vocab = os.path.join(opt.pretrained_path, "vocab.txt")
     if opt.vocab:
         if opt.vocab.endswith(".json"):
             vocab = json.load(open(opt.vocab))
@@ -131,8 +140,8 @@ def load_tokenizer(opt, memory):
 
 
 class _Log:
-    def __init__(self, path, rank):
-        self.fp = open(path, "w") if rank == 0 else None
+    def __init__(self, path, rank, append=False):
+        self.fp = open(path, "a" if append else "w") if rank == 0 else None
 
     def info(self, msg):
         if self.fp:
@@ -158,13 +167,16 @@ def main(argv=None):
     if opt.encoder_layers:
         cfg.num_hidden_layers = opt.encoder_layers
     if family == "bert":
-        cfg.vocab_size = max(opt.tokenizer.vocab_size, 8) if (opt.vocab or not opt.init_checkpoint) else cfg.vocab_size
+        if opt.vocab or not (opt.init_checkpoint or opt.pretrained_path):
+            cfg.vocab_size = max(opt.tokenizer.vocab_size, 8)
     model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=torch.bfloat16 if opt.dtype == "bf16" else torch.float32,
                           dropout=opt.dropout, seed=opt.random_seed)
     if opt.init_checkpoint:
         model.load_model(opt.init_checkpoint)
     else:
         model.load_reference_state(synth.model_state(cfg, labels, seed=opt.random_seed))
+        if opt.pretrained_path:
+            model.load_pretrained_encoder(opt.pretrained_path)
     trainer.broadcast_parameters(model)
     n_params = sum(s.numel for s in model.arena.slots)
     n_bert = sum(s.numel for s in model.arena.slots if "bert_encoder" in s.name)
@@ -179,7 +191,9 @@ def main(argv=None):
 
     def load(split, coverage=None):
         fn = os.path.join(opt.dataroot, split)
-        return trainer.read_wcn_data(fn, coverage) if os.path.exists(fn) else None
+        if not os.path.exists(fn):
+            return None
+        return trainer.EncodedSplit(trainer.read_wcn_data(fn, coverage), opt, memory)       # tokenised once per run
 
     valid, test = load(opt.valid_file), load(opt.test_file)
     if opt.testing:
@@ -198,13 +212,21 @@ def main(argv=None):
     train = load(opt.train_file, opt.coverage)
     if train is None:
         raise SystemExit("no training split at %s" % os.path.join(opt.dataroot, opt.train_file))
-    t_total = (len(train[0]) // opt.batchSize + 1) * opt.max_epoch            # n_best_asr_bert.py:556
+    t_total = (len(train) // opt.batchSize + 1) * opt.max_epoch            # n_best_asr_bert.py:556
     opt.optimizer = HipBertAdam(model, lr=opt.lr, bert_lr=opt.bert_lr, warmup=opt.warmup_proportion, t_total=t_total)
-    log = _Log(os.path.join(opt.exp_dir, "log.train"), rank)
+    log = _Log(os.path.join(opt.exp_dir, "log.train"), rank, append=opt.resume and os.path.exists(os.path.join(opt.exp_dir, "last.pt")))
     t_start = time.time()
     log.info("Training starts at %s" % time.asctime(time.localtime(t_start)))
     best = dict(epoch=0, vf=0.0, tef=0.0, v_acc=0.0, te_acc=0.0)
-    for ep in range(opt.max_epoch):
+    first_epoch, last = 0, os.path.join(opt.exp_dir, "last.pt")
+    if opt.resume and os.path.exists(last):
+        ck = torch.load(last, map_location="cpu", weights_only=True)           # written by this program: tensors + numbers
+        model.load_reference_state(ck["model"])
+        opt.optimizer.load_state_dict(ck["optimizer"])
+        best, first_epoch = ck["best"], ck["epoch"] + 1
+        model.step_counter = int(ck["dropout_step"])                           # dropout streams continue where they stopped
+        log.info("Resumed after epoch %02d (optimizer step %d)" % (ck["epoch"], opt.optimizer.step_count))
+    for ep in range(first_epoch, opt.max_epoch):
         t0 = time.time()
         loss, (p, r, f), acc = trainer.train_epoch(model, train, opt, memory, epoch=ep)
         log.info("[Train]\tEpoch: %02d\tTime: %.2f\tLoss: %.2f\t(p/r/f): (%.2f/%.2f/%.2f)\tAcc: %.2f" % (ep, time.time() - t0, loss, p, r, f, acc))
@@ -216,9 +238,12 @@ def main(argv=None):
             with (open(fn, "w") if rank == 0 else open(os.devnull, "w")) as fp, \
                     (open(fn + ".err", "w") if rank == 0 else open(os.devnull, "w")) as efp:
                 t0 = time.time()
-                loss, (p, r, f), acc, _ = trainer.eval_epoch(model, data, opt, memory, fp, efp)
+                loss, (p, r, f), acc, cases = trainer.eval_epoch(model, data, opt, memory, fp, efp)
             log.info("[%s]\tEpoch: %02d\tTime: %.2f\tLoss: %.2f\t(p/r/f): (%.2f/%.2f/%.2f)\tAcc: %.2f" % (
                 name.capitalize(), ep, time.time() - t0, loss, p, r, f, acc))
+            if rank == 0:                                                           # n_best_asr_bert.py:416,426
+                observe.observability_lens(observe.EpochInfoCollector.from_cases(cases, loss, (p, r, f), acc), ep, name,
+                                           opt.exp_dir, "tod_asr_bert_stc")
             res[name] = (f, acc)
         vf, v_acc = res.get("valid", (0.0, 0.0))
         tef, te_acc = res.get("test", (0.0, 0.0))
@@ -227,6 +252,14 @@ def main(argv=None):
             if rank == 0:
                 model.save_model(os.path.join(opt.exp_dir, "model.pt"))
             log.info("NEW BEST:\tEpoch: %02d\tvalid F1/Acc: %.2f/%.2f\ttest F1/Acc: %.2f/%.2f" % (ep, vf, v_acc, tef, te_acc))
+        if rank == 0 and opt.resume:
+            torch.save(dict(model={k: v.detach().cpu() for k, v in model.state_dict().items()},
+                            optimizer=opt.optimizer.state_dict(), best=best, epoch=ep, dropout_step=model.step_counter),
+                       last + ".tmp")
+            os.replace(last + ".tmp", last)
+        if opt.stop_after_epoch is not None and ep >= opt.stop_after_epoch:
+            log.info("Stopping after epoch %02d as requested" % ep)
+            return 0
     log.info("Done training. Elapsed time: %s" % timedelta(seconds=time.time() - t_start))
     log.info("BEST RESULT:\tEpoch: %02d\tBest valid F1/Acc: %.2f/%.2f\ttest F1/Acc: %.2f/%.2f" % (
         best["epoch"], best["vf"], best["v_acc"], best["tef"], best["te_acc"]))

@@ -262,9 +262,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         const T* __restrict__ dout, float* __restrict__ dword,
                                                         float* __restrict__ de_buf, float* __restrict__ part, int64_t M,
                                                         int H, int rows_per_block, int64_t word_pad_id, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];  // [2][H]
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [2][H] column partials | [waves][H] row restage
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, nvec = H >> 2;
   const float invH = 1.0f / (float)H;
+  float* rowbuf = acc + 2 * H + wave * H;
   for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) acc[i] = 0.f;
   __syncthreads();
   f32x4 ag[VPL], ab[VPL], gm[VPL];
@@ -311,13 +312,18 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
       if (c < nvec) {
         f32x4 o = (g[i] - s1 - xh[i] * s2) * rstd;
         *(f32x4*)(de_buf + row * H + 4 * c) = o;
-        if (id != word_pad_id) {
-          float* dw = dword + id * H + 4 * c;
-          atomicAdd(dw + 0, o[0]); atomicAdd(dw + 1, o[1]); atomicAdd(dw + 2, o[2]); atomicAdd(dw + 3, o[3]);
-        }
+        *(f32x4*)(rowbuf + 4 * c) = o;
         ag[i] += d[i] * xh[i];
         ab[i] += d[i];
       }
+    }
+    // scatter-add into the word table with lane-contiguous columns: every atomic wave-instruction covers 256
+    // contiguous bytes of one table row (the shape that runs at the full float-atomic rate)
+    if (id != word_pad_id) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float* dw = dword + id * H;
+      for (int col = lane; col < H; col += 64) atomicAdd(dw + col, rowbuf[col]);
+      asm volatile("" ::: "memory");
     }
   }
 #pragma unroll
@@ -548,7 +554,7 @@ extern "C" int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const 
   const int rpb = (int)((M + nblk - 1) / nblk);
   float* part = (float*)ws;
   float* de_buf = (float*)((char*)ws + nbest_rowred_ws_bytes(M, H));
-  const size_t smem = (size_t)2 * H * sizeof(float);
+  const size_t smem = (size_t)(2 + 4) * H * sizeof(float);
   if (dtype == NBEST_F32) {
     DISPATCH_VPL(H, (embed_bwd_kernel<float, VPL><<<nblk, 256, smem, st>>>(ids, seg, pos, (const float*)word, (const float*)type,
                                                                             (const float*)ptab, gamma, stats, (const float*)dout, dword,

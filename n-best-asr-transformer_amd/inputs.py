@@ -107,36 +107,53 @@ def cut_n_best(seq, n_best):
     return out
 
 
-def prepare_inputs_for_roberta(raw_in, tokenizer, opt, device, n_best=None):
+def encode_utterance(seq, tokenizer, opt, n_best=None, max_seq_len=None):
+    """one utterance -> (ids, seg | None) as python int lists, un-padded (bert_xlnet_inputs.py:20-85).
+
+    ``max_seq_len`` (build extension; the reference never truncates) cuts the tail hypotheses and re-closes the
+    sequence with the separator, so over-long n-best lists degrade to fewer hypotheses instead of failing."""
     family = getattr(opt, "pre_trained_model", None)
     tod = getattr(opt, "tod_pre_trained_model", None)
     no_sys = getattr(opt, "without_system_act", False)
     sep = tokenizer.sep_token
     first_sep = sep + sep if family == "xlm-roberta" else sep
-    rows, segs = [], []
-    for seq in raw_in:
-        seq = cut_n_best(list(seq), n_best)
-        usr = seq.index("[USR]")
-        a_words, b_words = seq[2:usr], seq[usr + 1:]            # drops "[CLS] [SYS]" (:24-28)
-        if tod:
-            a_words, b_words = ["[SYS]"] + a_words, ["[USR]"] + b_words
-        b_words = [first_sep if w == "[SEP]" else w for w in b_words]
-        a = [t for w in a_words for t in tokenizer.tokenize(w)]
-        b = [t for w in b_words for t in tokenizer.tokenize(w)]
-        if tod:
-            left, right = [tokenizer.cls_token] + a, b + [sep]
-        elif no_sys:
-            rows.append([tokenizer.cls_token] + b + [sep])
-            continue
-        else:
-            left, right = [tokenizer.cls_token] + a, [first_sep] + b + [sep]
-        rows.append(left + right)
-        segs.append([0] * len(left) + [1] * len(right))
-    lens = [len(r) for r in rows]
+    seq = cut_n_best(list(seq), n_best)
+    usr = seq.index("[USR]")
+    a_words, b_words = seq[2:usr], seq[usr + 1:]            # drops "[CLS] [SYS]" (:24-28)
+    if tod:
+        a_words, b_words = ["[SYS]"] + a_words, ["[USR]"] + b_words
+    b_words = [first_sep if w == "[SEP]" else w for w in b_words]
+    a = [t for w in a_words for t in tokenizer.tokenize(w)]
+    b = [t for w in b_words for t in tokenizer.tokenize(w)]
+    if tod:
+        left, right = [tokenizer.cls_token] + a, b + [sep]
+    elif no_sys:
+        left, right = [], [tokenizer.cls_token] + b + [sep]
+    else:
+        left, right = [tokenizer.cls_token] + a, [first_sep] + b + [sep]
+    toks = left + right
+    seg = None if (no_sys and not tod) else [0] * len(left) + [1] * len(right)
+    if max_seq_len and len(toks) > max_seq_len:
+        toks = toks[:max_seq_len - 1] + [sep]
+        seg = None if seg is None else seg[:max_seq_len - 1] + [1]
+    return tokenizer.convert_tokens_to_ids(toks), seg
+
+
+def collate(rows, pad_id, pin=False):
+    """[(ids, seg | None)] -> right-padded int64 host tensors ``ids [B,S]``, ``seg [B,S] | None`` and the lengths
+    (bert_xlnet_inputs.py:87-102: pad id for ids, 0 for segments, width = batch maximum)"""
+    lens = [len(r[0]) for r in rows]
     width = max(lens)
-    pad = tokenizer.pad_token_id
-    ids = torch.tensor([tokenizer.convert_tokens_to_ids(r) + [pad] * (width - len(r)) for r in rows], dtype=torch.long, device=device)
-    seg = None
-    if segs:
-        seg = torch.tensor([s + [0] * (width - len(s)) for s in segs], dtype=torch.long, device=device)
+    ids = torch.full((len(rows), width), pad_id, dtype=torch.long, pin_memory=pin)
+    seg = torch.zeros((len(rows), width), dtype=torch.long, pin_memory=pin) if rows[0][1] is not None else None
+    for i, (r, sg) in enumerate(rows):
+        ids[i, :len(r)] = torch.as_tensor(r, dtype=torch.long)
+        if seg is not None:
+            seg[i, :len(sg)] = torch.as_tensor(sg, dtype=torch.long)
     return ids, seg, lens
+
+
+def prepare_inputs_for_roberta(raw_in, tokenizer, opt, device, n_best=None, max_seq_len=None):
+    rows = [encode_utterance(seq, tokenizer, opt, n_best, max_seq_len) for seq in raw_in]
+    ids, seg, lens = collate(rows, tokenizer.pad_token_id)
+    return ids.to(device), (None if seg is None else seg.to(device)), lens

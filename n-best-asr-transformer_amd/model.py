@@ -110,6 +110,43 @@ class NBestSTCModel(nn.Module):
     def load_model(self, path):
         self.arena.load_state(torch.load(path, map_location="cpu", weights_only=True))
 
+    def load_pretrained_encoder(self, path):
+        """HF-format encoder weights from a LOCAL file or directory (model.safetensors / pytorch_model.bin) into the
+        arena: what ``Model.from_pretrained(name)`` gives the reference (n_best_asr_bert.py:480-487), minus the fetch.
+
+        Keys are matched after stripping the task prefix (``bert.`` / ``roberta.``) and renaming the TF-era
+        ``LayerNorm.gamma/beta``; MLM/NSP heads and position-id buffers in the file are ignored; the STC heads keep
+        their initialisation.  Returns the encoder tensors the file did not hold (the pooler may be absent).
+        """
+        import os
+        if os.path.isdir(path):
+            cands = [os.path.join(path, f) for f in ("model.safetensors", "pytorch_model.bin")]
+            found = [c for c in cands if os.path.exists(c)]
+            if not found:
+                raise FileNotFoundError("no model.safetensors / pytorch_model.bin under %s" % path)
+            path = found[0]
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            raw = load_file(path, device="cpu")
+        else:
+            raw = torch.load(path, map_location="cpu", weights_only=True)
+        sd = {}
+        for k, v in raw.items():
+            for pre in ("bert_encoder.", "bert.", "roberta.", "xlm_roberta."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+                    break
+            k = k.replace("LayerNorm.gamma", "LayerNorm.weight").replace("LayerNorm.beta", "LayerNorm.bias")
+            if k.startswith(("embeddings.", "encoder.", "pooler.")) and not k.endswith("position_ids"):
+                sd["bert_encoder." + k] = v
+        want = [s.name for s in self.arena.slots if s.name.startswith("bert_encoder.")]
+        missing = [n for n in want if n not in sd]
+        hard = [n for n in missing if "pooler" not in n]
+        if hard:
+            raise RuntimeError("checkpoint lacks encoder tensors: %s" % hard[:5])
+        self.arena.load_state(sd, strict=False)
+        return missing
+
     def _pass(self, B, S, slot):
         key = (B, S, slot)
         if key not in self._passes:

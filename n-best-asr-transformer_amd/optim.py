@@ -51,9 +51,17 @@ class HipBertAdam:
         self.step_count += 1
 
     def state_dict(self):
-        return dict(step=self.step_count, m=self.arena.m.cpu(), v=self.arena.v.cpu())
+        """per-parameter ``next_m`` / ``next_v`` keyed by parameter name plus the shared step count — the content of
+        the reference optimizer's ``state[p]`` (optimization.py:256-262,300), independent of the arena layout"""
+        a = self.arena
+        return dict(step=self.step_count, t_total=self.t_total, warmup=self.warmup,
+                    state={s.name: dict(next_m=a.view(a.m, s.name).detach().cpu().clone(),
+                                        next_v=a.view(a.v, s.name).detach().cpu().clone()) for s in a.slots})
 
     def load_state_dict(self, sd):
+        a = self.arena
         self.step_count = int(sd["step"])
-        self.arena.m.copy_(sd["m"])
-        self.arena.v.copy_(sd["v"])
+        for s in a.slots:
+            st = sd["state"][s.name]
+            a.view(a.m, s.name).copy_(st["next_m"])
+            a.view(a.v, s.name).copy_(st["next_v"])

@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 from .fscore import compute_f1, update_f1
-from .inputs import prepare_inputs_for_roberta
+from .inputs import collate, encode_utterance, prepare_inputs_for_roberta
 
 
 # ------------------------------------------------------------------------------------------------
@@ -92,6 +92,14 @@ class GradReducer:
         for w in self.pending:
             w.wait()
         self.pending = []
+
+    def contribute_nothing(self):
+        """a rank whose slice of a (short, final) batch is empty still joins every collective of the step, in the same
+        order as the ranks that ran a backward pass, with zero gradients"""
+        self.arena.g.zero_()
+        for lo, hi in reversed(self.chunks):
+            self.layers_ready(lo, hi)
+        self.wait()
 
 
 def train_step(model, optimizer, batch, add_l2_loss=False, add_segment_ids=True, reducer=None):
@@ -168,12 +176,25 @@ def pred_labels_from_indices(pred_row, idx2label):
     return [idx2label[j] for j in pred_row if j >= 0]
 
 
-def _host_metrics(model, out, raw_labels, idx2label, counts):
+def filter_informative(labels, ontology):
+    """n_best_asr_bert.py:218-229: keep act-slot-value labels only when the slot is ``this`` or an informable slot
+    with more than one value; labels of any other arity pass through"""
+    keep = []
+    for lbl in labels:
+        tup = lbl.split("-")
+        if len(tup) != 3 or tup[1] == "this" or (tup[1] in ontology["informable"] and len(ontology["informable"][tup[1]]) > 1):
+            keep.append(lbl)
+    return keep
+
+
+def _host_metrics(model, out, raw_labels, idx2label, counts, ontology=None):
     pred = model.decode(out["top"], out["bott"]).cpu().tolist()
     TP, FP, FN, corr, tot = counts
     all_preds = []
     for row, gold in zip(pred, raw_labels):
         pc = pred_labels_from_indices(row, idx2label)
+        if ontology is not None:                                          # eval only (:341-344)
+            pc, gold = filter_informative(pc, ontology), filter_informative(gold, ontology)
         TP, FP, FN = update_f1(pc, gold, TP, FP, FN)
         tot += 1
         corr += int(set(pc) == set(gold))
@@ -181,52 +202,175 @@ def _host_metrics(model, out, raw_labels, idx2label, counts):
     return (TP, FP, FN, corr, tot), all_preds
 
 
+class EncodedSplit:
+    """A data split tokenised ONCE.
+
+    The reference re-tokenises every word of every batch of every epoch in a Python loop
+    (bert_xlnet_inputs.py:46-53); at the step rates of the HIP path that loop is the bottleneck of real-data runs.
+    Here every utterance is converted to id / segment lists when the split is first used; a batch is then only a
+    gather + right-pad into pinned host buffers (inputs.collate).  Unpacks like the raw ``(asr, trans, labels)`` tuple.
+    """
+
+    def __init__(self, data, opt, memory):
+        self.asr, self.trans, self.labels = data
+        tok = opt.tokenizer
+        nb, msl = getattr(opt, "n_best", None), getattr(opt, "max_seq_len", None)
+        self.rows = [encode_utterance(s, tok, opt, nb, msl) for s in self.asr]
+        self.trows = [encode_utterance(s, tok, opt, None, msl) for s in self.trans]
+        l2i = memory["label2idx"]
+        self.y = torch.zeros(len(self.labels), len(l2i))
+        for i, ls in enumerate(self.labels):
+            for l in ls:
+                self.y[i, l2i.get(l, 1)] = 1                      # unknown label -> index 1, as labels_to_multihot
+        self.pad = tok.pad_token_id
+
+    def __iter__(self):
+        return iter((self.asr, self.trans, self.labels))
+
+    def __len__(self):
+        return len(self.asr)
+
+    def host_batch(self, idx, pin=False):
+        ids, seg, _ = collate([self.rows[j] for j in idx], self.pad, pin)
+        tids, tseg, _ = collate([self.trows[j] for j in idx], self.pad, pin)
+        y = self.y[torch.as_tensor(idx, dtype=torch.long)]
+        return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=y.pin_memory() if pin else y)
+
+
+def encoded(data, opt, memory):
+    return data if isinstance(data, EncodedSplit) else EncodedSplit(data, opt, memory)
+
+
+def batch_indices(n, batch_size, shuffle=False, seed=0):
+    order = np.arange(n)
+    if shuffle:
+        np.random.default_rng(seed).shuffle(order)
+    return [order[i:i + batch_size].tolist() for i in range(0, n, batch_size)]
+
+
+class Prefetcher:
+    """Iterates ``(batch_index, dataset indices of this rank's slice, device batch)`` one batch ahead of the consumer.
+
+    A worker thread collates batch i+1 into pinned host memory and enqueues its H2D copies on a side stream while the
+    GPU runs step i; the consumer's stream waits on the copy event only (no host synchronisation)."""
+
+    def __init__(self, split, index_lists, device, rank=0, world=1, depth=2):
+        import queue
+        import threading
+        self.split, self.lists, self.device, self.rank, self.world = split, index_lists, torch.device(device), rank, world
+        self.cuda = self.device.type == "cuda"
+        self.q = queue.Queue(maxsize=depth)
+        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.thread = threading.Thread(target=self._work, daemon=True)
+        self.thread.start()
+
+    def _work(self):
+        try:
+            for bi, idx in enumerate(self.lists):
+                lo, hi = shard_bounds(len(idx), self.rank, self.world)
+                if hi <= lo:
+                    self.q.put((bi, [], None, None))                 # nothing for this rank in this batch
+                    continue
+                mine = idx[lo:hi]
+                host = self.split.host_batch(mine, pin=self.cuda)
+                if not self.cuda:
+                    self.q.put((bi, mine, host, None))
+                    continue
+                with torch.cuda.stream(self.stream):
+                    dev = {k: (None if v is None else v.to(self.device, non_blocking=True)) for k, v in host.items()}
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                self.q.put((bi, mine, dev, (ev, host)))              # host buffers stay alive until the copy was waited on
+            self.q.put(None)
+        except BaseException as e:                                   # surface worker failures in the consumer
+            self.q.put(e)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            bi, mine, dev, sync = item
+            if sync is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(sync[0])
+                for v in dev.values():
+                    if v is not None:
+                        v.record_stream(cur)
+            yield bi, mine, dev
+
+
 def _prep(raw_in, raw_trans, raw_labels, opt, memory, device):
-    ids, seg, _ = prepare_inputs_for_roberta(raw_in, opt.tokenizer, opt, device, n_best=getattr(opt, "n_best", None))
-    tids, tseg, _ = prepare_inputs_for_roberta(raw_trans, opt.tokenizer, opt, device)
+    ids, seg, _ = prepare_inputs_for_roberta(raw_in, opt.tokenizer, opt, device, n_best=getattr(opt, "n_best", None),
+                                             max_seq_len=getattr(opt, "max_seq_len", None))
+    tids, tseg, _ = prepare_inputs_for_roberta(raw_trans, opt.tokenizer, opt, device, max_seq_len=getattr(opt, "max_seq_len", None))
     y = labels_to_multihot(raw_labels, memory["label2idx"], device)
     return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=y)
 
 
 def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
-    """n_best_asr_bert.py:232-294 -> (mean_loss, (p, r, f), acc).  ``data`` = (asr, trans, labels) lists."""
+    """n_best_asr_bert.py:232-294 -> (mean_loss, (p, r, f), acc).  ``data`` = (asr, trans, labels) lists or an
+    EncodedSplit (tokenised once; pass the same object every epoch to reuse it)."""
     model.train()
     rank, world = dist_info()
     reducer = GradReducer(model.arena) if (dist.is_available() and dist.is_initialized()) else None
     counts, losses = (0, 0, 0, 0, 0), []
-    for raw_in, raw_trans, raw_labels in batches(data, opt.batchSize, shuffle=shuffle, seed=getattr(opt, "random_seed", 999) + epoch):
-        lo, hi = shard_bounds(len(raw_in), rank, world)
-        if hi <= lo:
+    split = encoded(data, opt, memory)
+    lists = batch_indices(len(split), opt.batchSize, shuffle=shuffle, seed=getattr(opt, "random_seed", 999) + epoch)
+    for _, mine, b in Prefetcher(split, lists, model.device, rank, world):
+        if not mine:
+            if reducer is not None:
+                reducer.contribute_nothing()
+            opt.optimizer.step()                                     # keeps replicas and schedule positions identical
+            model.step_counter += 1
             continue
-        b = _prep(raw_in[lo:hi], raw_trans[lo:hi], raw_labels[lo:hi], opt, memory, model.device)
         out = train_step(model, opt.optimizer, b, add_l2_loss=opt.add_l2_loss, add_segment_ids=opt.add_segment_ids, reducer=reducer)
-        losses.append((out["loss_parts"], hi - lo))
-        counts, _ = _host_metrics(model, out, raw_labels[lo:hi], memory["idx2label"], counts)
+        losses.append((out["loss_parts"], len(mine)))
+        counts, _ = _host_metrics(model, out, [split.labels[j] for j in mine], memory["idx2label"], counts)
     return _finish(losses, counts, model.device)
+
+
+def merge_cases(chunks):
+    """[(batch_index, rank, cases)] of this rank -> all ranks' cases in dataset order (batch, then rank slice)"""
+    _, world = dist_info()
+    if world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, chunks)
+        chunks = sorted((c for part in every for c in part), key=lambda c: (c[0], c[1]))
+    return [case for _, _, part in chunks for case in part]
 
 
 @torch.no_grad()
 def eval_epoch(model, data, opt, memory, fp=None, efp=None):
-    """n_best_asr_bert.py:297-388 -> (mean_loss, (p, r, f), acc, cases); writes ``raw <=> pred <=> gold`` lines."""
+    """n_best_asr_bert.py:297-388 -> (mean_loss, (p, r, f), acc, cases); writes ``raw <=> pred <=> gold`` lines.
+
+    Under data parallelism every rank evaluates its slice of each batch; the per-utterance cases are gathered and put
+    back into dataset order, so ``cases`` and the lines written are the same on every rank as in a single process.
+    """
     model.eval()
     rank, world = dist_info()
-    counts, losses, cases = (0, 0, 0, 0, 0), [], []
-    for raw_in, raw_trans, raw_labels in batches(data, opt.batchSize):
-        lo, hi = shard_bounds(len(raw_in), rank, world)
-        if hi <= lo:
+    onto = getattr(opt, "ontology", None)
+    counts, losses, chunks = (0, 0, 0, 0, 0), [], []
+    split = encoded(data, opt, memory)
+    for bi, mine, b in Prefetcher(split, batch_indices(len(split), opt.batchSize), model.device, rank, world):
+        if not mine:
             continue
-        b = _prep(raw_in[lo:hi], raw_trans[lo:hi], raw_labels[lo:hi], opt, memory, model.device)
         seg = b["seg"] if opt.add_segment_ids else None
         out = model.forward_backward(b["ids"], b["labels"], seg_ids=seg, need_grad=False)     # no MSE in eval (:331)
-        losses.append((out["loss_parts"], hi - lo))
-        counts, preds = _host_metrics(model, out, raw_labels[lo:hi], memory["idx2label"], counts)
-        for raw, pc, gold in zip(raw_in[lo:hi], preds, raw_labels[lo:hi]):
-            line = "%s\t<=>\t%s\t<=>\t%s\n" % (" ".join(raw), ";".join(pc), ";".join(gold))
-            if fp is not None:
-                fp.write(line)
-            if efp is not None and set(pc) != set(gold):
-                efp.write(line)
-            cases.append((raw, pc, gold))
+        losses.append((out["loss_parts"], len(mine)))
+        raw_labels = [split.labels[j] for j in mine]
+        counts, preds = _host_metrics(model, out, raw_labels, memory["idx2label"], counts, onto)
+        golds = [filter_informative(g, onto) if onto is not None else g for g in raw_labels]
+        chunks.append((bi, rank, list(zip([split.asr[j] for j in mine], preds, golds))))
+    cases = merge_cases(chunks)
+    for raw, pc, gold in cases:
+        line = "%s\t<=>\t%s\t<=>\t%s\n" % (" ".join(raw), ";".join(pc), ";".join(gold))
+        if fp is not None:
+            fp.write(line)
+        if efp is not None and set(pc) != set(gold):
+            efp.write(line)
     return _finish(losses, counts, model.device) + (cases,)
 
 

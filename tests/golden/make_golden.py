@@ -110,6 +110,7 @@ def main():
         run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns)
     run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim)
     run_coverage_case()
+    run_observe_case()
 
 
 def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
@@ -360,5 +361,56 @@ def run_coverage_case():
         json.dump(out, f, indent=1)
 
 
+def run_observe_case():
+    """per-epoch CSV + per-label report (tod_asr_util.py:150-223) and the ontology filter (n_best_asr_bert.py:218-229)
+    on the gold annotations of the first 30 valid lines with deterministic prediction errors injected."""
+    import tempfile, io, contextlib
+    import utils.dataset.tod_asr_util as ref_data
+    from nbest_amd import observe, trainer
+    src = os.path.join(REF, "dstc2_data/processed_data/raw/valid")
+    with contextlib.redirect_stdout(io.StringIO()):
+        asr, _, gold = ref_data.read_wcn_data(src, 1.0)
+    asr, gold = [[str(w) for w in a] for a in asr[:30]], [[str(l) for l in g] for g in gold[:30]]
+    pool = sorted(set(l for g in gold for l in g)) + ["inform-food-neverseen", "zzz-unknown"]
+    preds = []
+    for i, g in enumerate(gold):
+        p = list(g)
+        if i % 3 == 1 and p:
+            p = p[1:]                                   # miss one
+        if i % 4 == 2:
+            p = p + [pool[(7 * i) % len(pool)]]         # spurious (sometimes a label no gold ever has)
+        if i % 11 == 5:
+            p = []
+        preds.append(p)
+    cases = [(a, p, g) for a, p, g in zip(asr, preds, gold)]
+    args = ([" ".join(a) for a in asr], preds, gold, [set(p) == set(g) for p, g in zip(preds, gold)],
+            1.2345678, 71.4285714, 66.6666667, 68.9655172, 41.6666667)
+    out = os.path.join(HERE, "observe")
+    os.makedirs(out, exist_ok=True)
+    ref_data.observability_lens(ref_data.EpochInfoCollector(*args), 3, "valid", out, "tod_asr_bert_stc")
+    with tempfile.TemporaryDirectory() as td:
+        observe.observability_lens(observe.EpochInfoCollector.from_cases(cases, args[4], args[5:8], args[8]), 3, "valid", td,
+                                   "tod_asr_bert_stc")
+        for fn in sorted(os.listdir(out)):
+            if fn.endswith(".json"):
+                continue
+            assert open(os.path.join(out, fn), "rb").read() == open(os.path.join(td, fn), "rb").read(), fn
+            print("   observability %s identical to the reference's" % fn)
+    onto = {"informable": {"food": ["a", "b"], "area": ["x", "y", "z"], "name": ["only"], "request": []}}
+    labs = ["inform-food-thai", "inform-name-x", "inform-this-dontcare", "request-slot-phone", "bye", "deny-pricerange-cheap",
+            "inform-area-north", "a-b-c-d"]
+    src = open(os.path.join(REF, "n_best_asr_bert.py")).read()
+    fns = {}
+    exec(compile(src[src.index("def filter_informative"):src.index("def train_epoch")], "n_best_asr_bert.py[218:230]", "exec"), fns)
+    flt = fns["filter_informative"](labs, onto)
+    assert trainer.filter_informative(labs, onto) == flt
+    with open(os.path.join(out, "inputs.json"), "w") as f:
+        json.dump(dict(raw=[" ".join(a) for a in asr], pred=preds, gold=gold, mean_loss=args[4], prf=list(args[5:8]), acc=args[8],
+                       ontology=onto, onto_labels=labs, onto_filtered=flt), f)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["observe"]:
+        run_observe_case()
+    else:
+        main()

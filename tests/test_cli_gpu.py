@@ -33,3 +33,86 @@ def test_cli_train_then_test(tmp_path):
     lines = open(os.path.join(d, "valid.iter1")).read().strip("\n").split("\n")
     assert len(lines) == 24 and all(l.count("\t<=>\t") == 2 for l in lines)
     assert lines[0].startswith("[CLS] [SYS] Hello , welcome")
+    # per-epoch observability files (tod_asr_util.py:200-222)
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(d, "epoch_1_for_valid_observe_tod_asr_bert_stc.csv"))))
+    assert len(rows) == 24 and rows[0]["dataset"] == "valid" and rows[0]["epoch"] == "1"
+    assert [r["raw_inputs"] for r in rows] == [l.split("\t<=>\t")[0] for l in lines]
+    rep = open(os.path.join(d, "classification_report_epoch_1_for_valid.txt")).read().split("\n")
+    assert rep[0].split() == ["label", "precision", "recall", "f1-score", "support"]
+    # --testing reloads model.pt and scores the splits
+    assert cli.main(common + ["--testing"]) == 0
+    assert "[Valid]\tTime:" in open(os.path.join(d, "log.test")).read()
+
+
+def _args(root, exp, extra):
+    return ["--dataset", "dstc2", "--dataroot", str(root), "--deviceId", "0", "--random_seed", "999", "--dropout", "0.3",
+            "--bert_dropout", "0.1", "--lr", "3e-5", "--bert_lr", "3e-5", "--batchSize", "16", "--max_epoch", "2", "--experiment", exp,
+            "--add_segment_ids", "--label_space", os.path.join(GOLDEN, "label_space.json"), "--dtype", "f32",
+            "--vocab", os.path.join(GOLDEN, "text_vocab.json"), "--encoder_layers", "2", "--n_best", "3", "--resume"] + extra
+
+
+def test_resume_continues_the_same_run(tmp_path):
+    """stop after epoch 0 and resume == two epochs in one go (weights, BertAdam moments, schedule position, dropout
+    streams and shuffle order all carry over); fp32 atomics in the embedding backward allow last-digit differences"""
+    import torch
+    import nbest_amd  # noqa: F401
+    from nbest_amd import cli
+    root = tmp_path / "data"
+    root.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "valid_head.txt"), root / "train")
+    shutil.copy(os.path.join(GOLDEN, "valid_head.txt"), root / "valid")
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    assert cli.main(_args(root, a, [])) == 0
+    assert cli.main(_args(root, b, ["--stop_after_epoch", "0"])) == 0
+    assert cli.main(_args(root, b, [])) == 0
+    da, db = cli.exp_dir(cli.parse_arguments(_args(root, a, []))), cli.exp_dir(cli.parse_arguments(_args(root, b, [])))
+    ca = torch.load(os.path.join(da, "last.pt"), weights_only=True)
+    cb = torch.load(os.path.join(db, "last.pt"), weights_only=True)
+    assert ca["epoch"] == cb["epoch"] == 1 and ca["optimizer"]["step"] == cb["optimizer"]["step"] == 4
+    for k in ca["model"]:
+        assert torch.allclose(ca["model"][k], cb["model"][k], rtol=0, atol=2e-6), k
+    k = "bert_encoder.encoder.layer.1.output.dense.weight"
+    assert torch.allclose(ca["optimizer"]["state"][k]["next_m"], cb["optimizer"]["state"][k]["next_m"], rtol=0, atol=1e-6)
+    log = open(os.path.join(db, "log.train")).read()
+    assert "Resumed after epoch 00 (optimizer step 2)" in log and log.count("[Train]\tEpoch: ") == 2
+
+
+def test_local_hf_checkpoint_loads(tmp_path, labels):
+    """HF-format safetensors with task prefix, MLM head and position-id buffer -> encoder arena (n_best_asr_bert.py:480-487)"""
+    import torch
+    from safetensors.torch import save_file
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=300)
+    sd = synth.model_state(cfg, labels, seed=5)
+    hf = {}
+    for k, v in sd.items():
+        if k.startswith("bert_encoder.") and "pooler" not in k:
+            k2 = "bert." + k[len("bert_encoder."):]
+            if "embeddings.LayerNorm" in k2:
+                k2 = k2.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+            hf[k2] = torch.as_tensor(v).contiguous()
+    hf["cls.predictions.bias"] = torch.zeros(300)
+    hf["bert.embeddings.position_ids"] = torch.arange(512).view(1, -1)
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    save_file(hf, str(ck / "model.safetensors"))
+    m = NBestSTCModel(cfg, labels, device="cuda:0", compute_dtype=torch.bfloat16)
+    m.load_reference_state(synth.model_state(cfg, labels, seed=6))
+    missing = m.load_pretrained_encoder(str(ck))
+    assert sorted(missing) == ["bert_encoder.pooler.dense.bias", "bert_encoder.pooler.dense.weight"]
+    got = m.state_dict()
+    other = synth.model_state(cfg, labels, seed=6)
+    for k, v in sd.items():
+        want = other[k] if ("pooler" in k or k.startswith("clf.")) else v
+        assert torch.equal(got[k].cpu(), torch.as_tensor(want).float()), k
+    a = m.arena
+    s = a.by_name["bert_encoder.encoder.layer.1.intermediate.dense.weight"]
+    assert torch.equal(a.w16[s.offset:s.offset + s.numel].float().cpu(), torch.as_tensor(sd[s.name]).to(torch.bfloat16).float().flatten())
+    bad = dict(hf)
+    del bad["bert.encoder.layer.0.output.dense.weight"]
+    save_file(bad, str(ck / "model.safetensors"))
+    with pytest.raises(RuntimeError, match="lacks encoder tensors"):
+        m.load_pretrained_encoder(str(ck))

@@ -49,6 +49,24 @@ def _worker(rank, world, port, q):
     ok = ok and abs(loss - 1.5) < 1e-9 and abs(acc - 100 * 3 / 8) < 1e-9 and abs(p - 100 * 7 / 9) < 1e-9
     lo, hi = trainer.shard_bounds(7, rank, world)
     ok = ok and (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
+    # short final batch: rank 1 has no utterance, joins the step's collectives with zeros and ends with rank 0's sums
+    red2 = trainer.GradReducer(a, n_chunks=2)
+    if rank == 0:
+        a.g.copy_(local)
+        for lo_, hi_ in reversed(red2.chunks):
+            red2.layers_ready(lo_, hi_)
+        red2.wait()
+    else:
+        red2.contribute_nothing()
+    ref0 = local.clone()
+    dist.broadcast(ref0, src=0)
+    for lo_, hi_ in [a.heads_range, a.emb_range] + [(a.layer_range[l][0], a.layer_range[l][1]) for l in range(len(a.layer_range))]:
+        ok = ok and torch.equal(a.g[lo_:hi_], ref0[lo_:hi_])
+    # eval cases: every rank holds its slice of each batch; merged list = dataset order on every rank
+    mine = [(b, rank, [("b%d" % b, "r%d" % rank, i) for i in range(2 - rank + b % 2)]) for b in range(3)]
+    merged = trainer.merge_cases(mine)
+    want = [("b%d" % b, "r%d" % r, i) for b in range(3) for r in range(2) for i in range(2 - r + b % 2)]
+    ok = ok and merged == want
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

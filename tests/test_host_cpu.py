@@ -153,3 +153,51 @@ def test_arena_layout(labels):
     np.testing.assert_array_equal(Wh[30:105].numpy(), sd["clf.linear_layers.lin_2.weight"])
     lo, hi = a.layer_range[1]
     assert lo == a.layer_offsets[1].wqkv and hi > a.layer_offsets[1].ln2_b
+
+
+def test_observability_files_match_reference(tmp_path):
+    """per-epoch CSV + per-label report (tod_asr_util.py:150-223) byte-for-byte against files the reference wrote for the
+    same cases; ontology filter (n_best_asr_bert.py:218-229) against the reference's output"""
+    import json
+    from nbest_amd import observe, trainer
+    g = os.path.join(os.path.dirname(__file__), "golden", "observe")
+    d = json.load(open(os.path.join(g, "inputs.json")))
+    cases = [(r.split(" "), p, gd) for r, p, gd in zip(d["raw"], d["pred"], d["gold"])]
+    eic = observe.EpochInfoCollector.from_cases(cases, d["mean_loss"], d["prf"], d["acc"])
+    observe.observability_lens(eic, 3, "valid", str(tmp_path), "tod_asr_bert_stc")
+    for fn in ("classification_report_epoch_3_for_valid.txt", "epoch_3_for_valid_observe_tod_asr_bert_stc.csv"):
+        assert open(os.path.join(g, fn), "rb").read() == open(os.path.join(str(tmp_path), fn), "rb").read(), fn
+    assert trainer.filter_informative(d["onto_labels"], d["ontology"]) == d["onto_filtered"]
+
+
+def test_encoded_split_and_prefetcher_match_per_batch_builder(labels):
+    """tokenise-once split + prefetching iterator produce exactly the tensors of the per-batch
+    builder, in order, for every rank's slice; max_seq_len truncation re-closes the sequence"""
+    from nbest_amd import trainer
+    vocab = json.load(open(os.path.join(GOLDEN, "text_vocab.json")))
+    tok = inputs.WordPieceTokenizer(vocab)
+    data = trainer.read_wcn_data(os.path.join(GOLDEN, "valid_head.txt"))
+    memory = dict(label2idx={l: i for i, l in enumerate(labels.idx2label)})
+    opt = type("O", (), dict(tokenizer=tok, pre_trained_model="bert", n_best=4, max_seq_len=None))()
+    split = trainer.EncodedSplit(data, opt, memory)
+    lists = trainer.batch_indices(len(split), 7, shuffle=True, seed=3)
+    assert sorted(j for l in lists for j in l) == list(range(24))
+    for world in (1, 2):
+        for rank in range(world):
+            seen = 0
+            for bi, mine, b in trainer.Prefetcher(split, lists, "cpu", rank, world):
+                lo, hi = trainer.shard_bounds(len(lists[bi]), rank, world)
+                assert mine == lists[bi][lo:hi]
+                ids, seg, _ = inputs.prepare_inputs_for_roberta([data[0][j] for j in mine], tok, opt, "cpu", n_best=4)
+                tids, _, _ = inputs.prepare_inputs_for_roberta([data[1][j] for j in mine], tok, opt, "cpu")
+                y = trainer.labels_to_multihot([data[2][j] for j in mine], memory["label2idx"], "cpu")
+                assert torch.equal(b["ids"], ids) and torch.equal(b["seg"], seg) and torch.equal(b["tids"], tids)
+                assert torch.equal(b["labels"], y)
+                seen += 1
+            assert seen == len(lists)
+    # a rank with an empty slice still sees the batch (it must join that step's collectives)
+    got = [(bi, mine) for bi, mine, _ in trainer.Prefetcher(split, [[0], [1, 2]], "cpu", 1, 2)]
+    assert got == [(0, []), (1, [2])]
+    full, _ = inputs.encode_utterance(data[0][0], tok, opt)
+    cut, seg = inputs.encode_utterance(data[0][0], tok, opt, max_seq_len=20)
+    assert len(full) > 20 and len(cut) == 20 and cut[:19] == full[:19] and cut[-1] == vocab.index("[SEP]") and len(seg) == 20
