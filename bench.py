@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--seq_len", type=int, default=128)
     ap.add_argument("--n_best", type=int, default=5)
-    ap.add_argument("--model", default="bert", choices=["bert", "xlm-roberta"])
+    ap.add_argument("--model", default="bert", choices=["bert", "xlm-roberta", "xlm-roberta-large"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--add_l2_loss", action="store_true")
     ap.add_argument("--no_dropout", action="store_true")
@@ -182,7 +182,7 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %s shape (random init), %s, synthetic n_best=%d seq_len=%d, batch %d per GPU, "
                                    "fwd+losses+bwd+allreduce+BertAdam, dropout %s" % (
-                                       "bert-base-uncased" if a.model == "bert" else "xlm-roberta-base", a.dtype, a.n_best, a.seq_len,
+                                       {"bert": "bert-base-uncased", "xlm-roberta": "xlm-roberta-base"}.get(a.model, a.model), a.dtype, a.n_best, a.seq_len,
                                        a.batch, "off" if a.no_dropout else "on (0.1/0.1/0.3)"),
                        "global_batch": a.batch * world, "seq_len": a.seq_len, "n_best": a.n_best, "parallelism": "dp%d" % world,
                        "add_l2_loss": bool(a.add_l2_loss)},

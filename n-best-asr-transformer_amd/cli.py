@@ -52,7 +52,7 @@ def parse_arguments(argv=None):
     g.add_argument("--train_file", default="train")
     g.add_argument("--valid_file", default="valid")
     g.add_argument("--test_file", default="test")
-    g.add_argument("--ontology_path", default=None)
+    g.add_argument("--ontology_path", default=None, help="ontology JSON: evaluation keeps informative act-slot-value labels only")
     g = ap.add_argument_group("encoder")
     g.add_argument("--bert_model_name", default="bert-base-uncased")
     g.add_argument("--fix_bert_model", action="store_true")
@@ -80,7 +80,6 @@ def parse_arguments(argv=None):
     g.add_argument("--add_l2_loss", action="store_true")
     g.add_argument("--without_system_act", action="store_true")
     g.add_argument("--add_segment_ids", action="store_true")
-    g.add_argument("--ontology_path", default=None, help="ontology JSON: evaluation keeps informative act-slot-value labels only")
     g = ap.add_argument_group("additive flags of this build")
     g.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     g.add_argument("--n_best", type=int, default=None, help="keep only the first n hypotheses of every utterance")

@@ -45,7 +45,9 @@ def xlmr_base(**kw):
 
 
 def xlmr_large(**kw):
-    return xlmr_base(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, **kw)
+    large = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    large.update(kw)
+    return xlmr_base(**large)
 
 
 NAMED = {"bert": bert_base, "bert-base-uncased": bert_base, "xlm-roberta": xlmr_base,

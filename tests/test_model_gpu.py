@@ -157,10 +157,25 @@ def _oracle_for(cfg, sd, labels):
 def test_edge_shapes_match_oracle(B, S, St, dtype, labels):
     """ragged / tiny / maximum-length batches (S = 5 .. 256, single utterance) against the oracle on the same inputs"""
     import nbest_amd  # noqa: F401
-    from nbest_amd import config as ncfg, synth
+    from nbest_amd import config as ncfg
+    cfg = ncfg.bert_base(num_hidden_layers=1, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    _check_vs_oracle(cfg, B, S, St, dtype, labels)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_xlmr_large_shape_matches_oracle(dtype, labels):
+    """BASELINE configs[4] architecture (H=1024, 16 heads, FFN 4096, XLM-R embeddings / pad-offset positions), 2 layers"""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg
+    cfg = ncfg.xlmr_large(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    assert (cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size) == (1024, 16, 4096)
+    _check_vs_oracle(cfg, 3, 72, 24, dtype, labels)
+
+
+def _check_vs_oracle(cfg, B, S, St, dtype, labels):
+    from nbest_amd import synth
     from nbest_amd.model import NBestSTCModel
     from oracle import stc
-    cfg = ncfg.bert_base(num_hidden_layers=1, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     sd = synth.model_state(cfg, labels, seed=31)
     n_best = 2 if S < 16 else 5
     batch = synth.nbest_batch(cfg, labels, B, S, n_best=n_best, seed=S, ragged=True, trans_len=St)
