@@ -102,6 +102,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// two full-wave sums at once: four DPP steps inside each row of 16 lanes (no LDS crossbar), then two xor-shuffles
+// across the rows; the two dependency chains interleave.  Every lane gets both totals.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+  a = dpp_add<0xB1>(a); b = dpp_add<0xB1>(b);     // quad_perm [1,0,3,2]
+  a = dpp_add<0x4E>(a); b = dpp_add<0x4E>(b);     // quad_perm [2,3,0,1]
+  a = dpp_add<0x141>(a); b = dpp_add<0x141>(b);   // row_half_mirror
+  a = dpp_add<0x140>(a); b = dpp_add<0x140>(b);   // row_mirror
+  a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+  a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

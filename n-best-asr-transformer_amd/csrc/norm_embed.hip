@@ -7,10 +7,12 @@
 // Column reductions (dgamma, dbeta, bias gradients) are deterministic: per-block partial rows in a
 // workspace + a finalize kernel (no float atomics on the gradient of a parameter).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int kMaxRowredBlocks = 512;
+constexpr int kMaxLnBwdBlocks = 1024;   // the LayerNorm backward may use more, smaller row blocks (workspace is sized for it)
 static inline int rowred_blocks(int64_t M) {
   int64_t b = (M + 31) / 32;
   if (b < 1) b = 1;
@@ -140,24 +142,148 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
+  // the waves add their column sums into the block's LDS row one after the other (plain read-modify-write:
+  // LDS float atomics cost ~10 us per workgroup here)
+  for (int w = 0; w < wpb; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nvec) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(&acc[4 * c + e], ag[i][e]);
-        atomicAdd(&acc[H + 4 * c + e], ab[i][e]);
-        if (with_dbias) atomicAdd(&acc[2 * H + 4 * c + e], ad[i][e]);
+      for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+          *(f32x4*)&acc[4 * c] += ag[i];
+          *(f32x4*)&acc[H + 4 * c] += ab[i];
+          if (with_dbias) *(f32x4*)&acc[2 * H + 4 * c] += ad[i];
+        }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   const int nblk = gridDim.x;
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
     part[((int64_t)0 * nblk + blockIdx.x) * H + i] = acc[i];
     part[((int64_t)1 * nblk + blockIdx.x) * H + i] = acc[H + i];
     if (with_dbias) part[((int64_t)2 * nblk + blockIdx.x) * H + i] = acc[2 * H + i];
+  }
+}
+
+// ---- bf16 fast path of the LayerNorm backward: H == VPL*256, no bounds checks, no divergent branches ----------
+// The generic kernel above spends ~500 VALU instructions per row (exec-mask branches around every vector, register
+// shuffles, six LDS-crossbar shuffles per reduction) and was VALU-issue bound at two waves per SIMD (59 us for 200 MB).
+// Here: packed-pair fp32 math, bf16 pairs unpacked with one shift / one mask, DPP reductions, the dropout hash input
+// formed by addition from a per-row scalar base, compile-time DROP / DBIAS, conflict-free LDS accumulation.
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) {
+  return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(f32x2 v) {
+  bf16x2 o;
+  o[0] = (bf16)v[0]; o[1] = (bf16)v[1];
+  return __builtin_bit_cast(uint32_t, o);
+}
+
+template <int VPL, bool DROP, bool DBIAS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ln_bwd_fast_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          bf16* __restrict__ dx, bf16* __restrict__ dx_drop,
+                                                          float* __restrict__ part, int64_t M, int rows_per_block, DropCfg drop) {
+  constexpr int H = VPL * 256;
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // [wave][k][e][i][lane]: every wave parks its column sums here
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x2 gm[VPL][2], ag[VPL][2], ab[VPL][2], ad[VPL][2];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const f32x4 g4 = *(const f32x4*)(gamma + 4 * (lane + 64 * i));
+    gm[i][0] = f32x2{g4[0], g4[1]}; gm[i][1] = f32x2{g4[2], g4[3]};
+    ag[i][0] = ag[i][1] = ab[i][0] = ab[i][1] = ad[i][0] = ad[i][1] = f32x2{0.f, 0.f};
+  }
+  // rows are dealt round-robin over ALL waves of the grid (rows_per_block < 0: stride = -rows_per_block), so at any
+  // moment the grid streams one contiguous window of the tensors instead of gridDim.x*4 separate ones
+  const int64_t stride = rows_per_block < 0 ? -(int64_t)rows_per_block : WAVES;
+  const int64_t r0 = rows_per_block < 0 ? (int64_t)blockIdx.x * WAVES : (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = rows_per_block < 0 ? M : ((r0 + rows_per_block < M) ? r0 + rows_per_block : M);
+  constexpr float invH = 1.0f / (float)H;
+  int64_t row = r0 + wave;
+  if (row < r1) {
+    uint2 nx[VPL], nd[VPL];
+    float nmean = stats[2 * row], nrstd = stats[2 * row + 1];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      nx[i] = *(const uint2*)(x + row * H + 4 * (lane + 64 * i));
+      nd[i] = *(const uint2*)(dy + row * H + 4 * (lane + 64 * i));
+    }
+    for (; row < r1; row += stride) {
+      const float mean = nmean, rstd = nrstd;
+      uint2 cx[VPL], cd[VPL];
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; }
+      {  // next row (clamped: the last iteration re-reads its own row instead of branching)
+        const int64_t nrow = (row + stride < r1) ? row + stride : row;
+        nmean = stats[2 * nrow]; nrstd = stats[2 * nrow + 1];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+          nx[i] = *(const uint2*)(x + nrow * H + 4 * (lane + 64 * i));
+          nd[i] = *(const uint2*)(dy + nrow * H + 4 * (lane + 64 * i));
+        }
+      }
+      const float mr = -mean * rstd;
+      f32x2 xh[VPL][2], d[VPL][2], g[VPL][2];
+      f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        xh[i][0] = unpack_bf16x2(cx[i].x) * rstd + mr; xh[i][1] = unpack_bf16x2(cx[i].y) * rstd + mr;
+        d[i][0] = unpack_bf16x2(cd[i].x); d[i][1] = unpack_bf16x2(cd[i].y);
+        g[i][0] = d[i][0] * gm[i][0]; g[i][1] = d[i][1] * gm[i][1];
+        p1 += g[i][0]; p1 += g[i][1];
+        p2 += g[i][0] * xh[i][0]; p2 += g[i][1] * xh[i][1];
+      }
+      float s1 = p1[0] + p1[1], s2 = p2[0] + p2[1];
+      wave_sum2(s1, s2);
+      const float a1 = -s1 * invH * rstd, a2 = -s2 * invH * rstd;
+      const uint32_t hbase = (uint32_t)((row * H) >> 1) * 0x9E3779B9U + drop.key;   // hash input of the row's first pair
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        f32x2 o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) o[h] = xh[i][h] * a2 + (g[i][h] * rstd + a1);
+        const int64_t off = row * H + 4 * (lane + 64 * i);
+        *(uint2*)(dx + off) = uint2{pack_bf16x2(o[0]), pack_bf16x2(o[1])};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { ag[i][h] += d[i][h] * xh[i][h]; ab[i][h] += d[i][h]; }
+        if (DROP) {
+          const uint32_t q = (uint32_t)(2 * (lane + 64 * i));   // pair index inside the row
+          const uint32_t h0 = nb_hash32(hbase + q * 0x9E3779B9U), h1 = nb_hash32(hbase + (q + 1) * 0x9E3779B9U);
+          o[0][0] = ((h0 & 0xFFFFu) >= drop.thr16) ? o[0][0] * drop.scale : 0.f;
+          o[0][1] = ((h0 >> 16) >= drop.thr16) ? o[0][1] * drop.scale : 0.f;
+          o[1][0] = ((h1 & 0xFFFFu) >= drop.thr16) ? o[1][0] * drop.scale : 0.f;
+          o[1][1] = ((h1 >> 16) >= drop.thr16) ? o[1][1] * drop.scale : 0.f;
+          *(uint2*)(dx_drop + off) = uint2{pack_bf16x2(o[0]), pack_bf16x2(o[1])};
+        }
+        if (DBIAS) { ad[i][0] += o[0]; ad[i][1] += o[1]; }
+      }
+    }
+  }
+  float* mine = acc + wave * 3 * H;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int a = (e * VPL + i) * 64 + lane;
+      mine[a] = ag[i][e >> 1][e & 1];
+      mine[H + a] = ab[i][e >> 1][e & 1];
+      if (DBIAS) mine[2 * H + a] = ad[i][e >> 1][e & 1];
+    }
+  __syncthreads();
+  const int nblk = gridDim.x;
+  for (int col = threadIdx.x; col < H; col += WAVES * 64) {
+    const int chunk = col >> 2, e = col & 3, a = (e * VPL + (chunk >> 6)) * 64 + (chunk & 63);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      t0 += acc[w * 3 * H + a]; t1 += acc[w * 3 * H + H + a];
+      if (DBIAS) t2 += acc[w * 3 * H + 2 * H + a];
+    }
+    part[((int64_t)0 * nblk + blockIdx.x) * H + col] = t0;
+    part[((int64_t)1 * nblk + blockIdx.x) * H + col] = t1;
+    if (DBIAS) part[((int64_t)2 * nblk + blockIdx.x) * H + col] = t2;
   }
 }
 
@@ -326,18 +452,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
       asm volatile("" ::: "memory");
     }
   }
+  for (int w = 0; w < wpb; ++w) {   // waves take turns (no LDS float atomics, see ln_bwd_kernel)
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nvec) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(&acc[4 * c + e], ag[i][e]);
-        atomicAdd(&acc[H + 4 * c + e], ab[i][e]);
+      for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+          *(f32x4*)&acc[4 * c] += ag[i];
+          *(f32x4*)&acc[H + 4 * c] += ab[i];
+        }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   const int nblk = gridDim.x;
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
     part[((int64_t)0 * nblk + blockIdx.x) * H + i] = acc[i];
@@ -453,7 +580,12 @@ int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* 
   return finalize(part, nrows, N, out, accumulate, nullptr, 0, nullptr, 0, st);
 }
 
-extern "C" size_t nbest_rowred_ws_bytes(int64_t M, int64_t N) { return (size_t)3 * rowred_blocks(M) * N * sizeof(float); }
+extern "C" size_t nbest_rowred_ws_bytes(int64_t M, int64_t N) {
+  int64_t b = (M + 31) / 32;
+  if (b < 1) b = 1;
+  if (b > kMaxLnBwdBlocks) b = kMaxLnBwdBlocks;
+  return (size_t)3 * b * N * sizeof(float);
+}
 extern "C" size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H) {
   return nbest_rowred_ws_bytes(M, H) + (size_t)M * H * sizeof(float);
 }
@@ -484,14 +616,42 @@ extern "C" int nbest_layernorm_bwd(const void* dy, const void* x, const float* s
   NB_CHECK(d.thr16 == 0 || (dx_drop && dx_drop != dx), NBEST_ERR_ARG, "layernorm_bwd: dropout needs a separate dx_drop buffer");
   NB_CHECK(M * (int64_t)H < (int64_t)1 << 32 || d.thr16 == 0, NBEST_ERR_SHAPE, "layernorm_bwd: dropout counter overflow");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = rowred_blocks(M);
-  const int rpb = (int)((M + nblk - 1) / nblk);
+  int nblk = (int)((M + 31) / 32 < 1 ? 1 : ((M + 31) / 32 > kMaxLnBwdBlocks ? kMaxLnBwdBlocks : (M + 31) / 32));
+  if (nblk > 512) nblk = 512;   // measured: 256 and 512 blocks tie (32 us for 200 MB), 1024 loses to the longer finalize
+  int rpb = (int)((M + nblk - 1) / nblk);
+  nblk = (int)((M + rpb - 1) / rpb);
+  constexpr int waves = 4;
   float* part = (float*)ws;
   const size_t smem = (size_t)3 * H * sizeof(float);
   const int wb = dbias ? 1 : 0;
   if (dtype == NBEST_F32) {
     DISPATCH_VPL(H, (ln_bwd_kernel<float, VPL><<<nblk, 256, smem, st>>>((const float*)dy, (const float*)x, stats, gamma,
                                                                          (float*)dx, (float*)dx_drop, part, M, H, rpb, wb, d)));
+  } else if (dtype == NBEST_BF16 && H % 256 == 0 && H <= 1024) {
+#define NB_LNB(V, D, B)                                                                                                        \
+  do {                                                                                                                         \
+    if (waves == 8) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)ln_bwd_fast_kernel<V, D, B, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * H * 4); \
+      ln_bwd_fast_kernel<V, D, B, 8><<<nblk, 512, 8 * 3 * H * 4, st>>>((const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx,       \
+                                                                       (bf16*)dx_drop, part, M, rpb, d);                       \
+    } else {                                                                                                                   \
+      ln_bwd_fast_kernel<V, D, B, 4><<<nblk, 256, 4 * 3 * H * 4, st>>>((const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx,       \
+                                                                       (bf16*)dx_drop, part, M, rpb, d);                       \
+    }                                                                                                                          \
+  } while (0)
+#define NB_LNB_V(V)                                                     \
+  do {                                                                  \
+    if (d.thr16) { if (wb) NB_LNB(V, true, true); else NB_LNB(V, true, false); } \
+    else { if (wb) NB_LNB(V, false, true); else NB_LNB(V, false, false); }       \
+  } while (0)
+    switch (H / 256) {
+      case 1: NB_LNB_V(1); break;
+      case 2: NB_LNB_V(2); break;
+      case 3: NB_LNB_V(3); break;
+      default: NB_LNB_V(4); break;
+    }
+#undef NB_LNB_V
+#undef NB_LNB
   } else if (dtype == NBEST_BF16) {
     DISPATCH_VPL(H, (ln_bwd_kernel<bf16, VPL><<<nblk, 256, smem, st>>>((const bf16*)dy, (const bf16*)x, stats, gamma,
                                                                         (bf16*)dx, (bf16*)dx_drop, part, M, H, rpb, wb, d)));
