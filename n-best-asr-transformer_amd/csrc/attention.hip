@@ -257,17 +257,32 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     if (hh == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = mxs + __logf(sum);
+    if (drop.thr16 && (S & 1) == 0) {
+      // registers (2j, 2j+1) hold keys (k, k+1) with k even: with S even they are one element pair of the counter
+      // stream, so one hash decides both
+      const uint32_t rowbase = (uint32_t)((bh * S + qrow) * S);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pv = sc[kb][r] * inv;
-        if (drop.thr16) {
-          const int key = 32 * kb + crow(r, hh);
-          pv = nb_keep(drop, (uint32_t)((bh * S + qrow) * S + key)) ? pv * drop.scale : 0.f;
+        for (int r = 0; r < 16; r += 2) {
+          const uint32_t idx = rowbase + (uint32_t)(32 * kb + crow(r, hh));
+          const uint32_t hsh = nb_hash32((idx >> 1) * 0x9E3779B9U + drop.key);
+          sc[kb][r] = ((hsh & 0xFFFFu) >= drop.thr16) ? sc[kb][r] * (inv * drop.scale) : 0.f;
+          sc[kb][r + 1] = ((hsh >> 16) >= drop.thr16) ? sc[kb][r + 1] * (inv * drop.scale) : 0.f;
         }
-        sc[kb][r] = pv;
-      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = sc[kb][r] * inv;
+          if (drop.thr16) {
+            const int key = 32 * kb + crow(r, hh);
+            pv = nb_keep(drop, (uint32_t)((bh * S + qrow) * S + key)) ? pv * drop.scale : 0.f;
+          }
+          sc[kb][r] = pv;
+        }
+    }
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
