@@ -138,24 +138,53 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed for every wave; every wave is done reading the other stage
     const char* cur = lds + (kt & 1) * kStageBytes;
-    if (kt + 1 < nk) {
-      char* nxt = lds + ((kt + 1) & 1) * kStageBytes;
-      const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
-      stage_tile<TA>(rsA, nxt, m0, k0, p.lda, tid);
-      stage_tile<TB>(rsB, nxt + kTileBytes, n0, k0, p.ldb, tid);
-    }
+    if constexpr (TA || TB) {
+      // Transposed operands: the compiler cannot prove that a ds_read_b64_tr_b16 does not alias an LDS-DMA still in
+      // flight and puts `s_waitcnt vmcnt(0)` in front of the first transposed read that follows a DMA issue in
+      // program order - which used to drain tile kt+1 before tile kt was multiplied (no load/compute overlap at
+      // all inside a workgroup).  So: read EVERY fragment of tile kt first, issue the DMA of tile kt+1 after the
+      // last read, then multiply.  64 fragment registers; the accumulators live in AGPRs.
+      bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(cur, wm * 64 + i * 16, ks, lane);
+        for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<TA>(cur, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(cur + kTileBytes, wn * 64 + j * 16, ks, lane);
+        for (int j = 0; j < 4; ++j) bfr[ks][j] = read_frag<TB>(cur + kTileBytes, wn * 64 + j * 16, ks, lane);
+      }
+      if (kt + 1 < nk) {
+        char* nxt = lds + ((kt + 1) & 1) * kStageBytes;
+        const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
+        stage_tile<TA>(rsA, nxt, m0, k0, p.lda, tid);
+        stage_tile<TB>(rsB, nxt + kTileBytes, n0, k0, p.ldb, tid);
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    } else {
+      if (kt + 1 < nk) {
+        char* nxt = lds + ((kt + 1) & 1) * kStageBytes;
+        const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
+        stage_tile<TA>(rsA, nxt, m0, k0, p.lda, tid);
+        stage_tile<TB>(rsB, nxt + kTileBytes, n0, k0, p.ldb, tid);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(cur, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(cur + kTileBytes, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
     }
   }
 
