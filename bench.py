@@ -29,7 +29,7 @@ from nbest_amd.trainer import GradReducer, broadcast_parameters, init_distribute
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
 # KiB -> bytes), measured on configs[1]; see profiles/README.md.  None until measured.
-TRAFFIC_BYTES_PER_LAUNCH = 416.5e6   # (2 x 175 430 KiB FETCH_SIZE + 55 874 KiB WRITE_SIZE) x 1024, avg of the layer's 4 launches
+TRAFFIC_BYTES_PER_LAUNCH = 332.8e6   # (2 x 134 460 KiB FETCH_SIZE + 56 081 KiB WRITE_SIZE) x 1024, avg of the layer's 4 launches
 
 
 def flops_per_utt(cfg, S, St=0):
@@ -71,7 +71,9 @@ def cpu_baseline(labels, seconds_budget=25.0):
 
 def time_dominant_kernel(M, H, F, iters=10):
     """The kernel with the largest share of the step (rocprof: profiles/): the weight-gradient GEMM
-    gemm_bf16_kernel<true,true,F32_SPLITK> (dW = dY^T . X over the M = B*S token rows, split-K, fp32 out).
+    (dW = dY^T . X over the M = B*S token rows, split-K, fp32 out; the 256x256 ping-pong kernel
+    gemm2_kernel<...,true,true,F32_SPLITK> for the QKV / FFN gradients, gemm_bf16_kernel<true,true,F32_SPLITK> for the
+    768x768 attention-output gradient).
     It is launched four times per layer (QKV, attention-out, FFN-up, FFN-down); this times that set on the
     launch stream with HIP events and returns (avg ms per launch, avg algorithmic flops per launch,
     avg algorithmic bytes per launch = both bf16 operands read once + the fp32 gradient written once)."""
@@ -195,8 +197,12 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
-                               "kernel": "gemm_bf16_kernel<true,true,F32_SPLITK> (weight gradients dW = dY^T.X, K = %d token rows; "
-                                         "avg over the 4 launches of a layer: 2304x768, 768x768, 3072x768, 768x3072)" % (a.batch * a.seq_len),
+                               "kernel": "weight-gradient GEMM dW = dY^T.X (both operands token-major, transposed LDS reads, split-K, fp32 "
+                                         "out; gemm2_kernel<256,256,...,true,true,F32_SPLITK> for QKV/FFN, gemm_bf16_kernel<true,true,"
+                                         "F32_SPLITK> for the attention output), K = %d token rows; avg over the 4 launches of a layer: "
+                                         "%dx%d, %dx%d, %dx%d, %dx%d" % (a.batch * a.seq_len, 3 * cfg.hidden_size, cfg.hidden_size,
+                                                                        cfg.hidden_size, cfg.hidden_size, cfg.intermediate_size,
+                                                                        cfg.hidden_size, cfg.hidden_size, cfg.intermediate_size),
                                "avg_launch_ms": round(ms, 4), "flops_per_launch": fl, "algorithmic_bytes_per_launch": by}
         if world == 1 and not a.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")

@@ -67,8 +67,19 @@ __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* til
   }
 }
 
+// ds_read_b64_tr_b16 through inline asm.  The builtin is treated as a read of unknown LDS memory: with LDS-DMA
+// loads still in flight (the whole point of the ring) the compiler puts `s_waitcnt vmcnt(0)` in front of it and
+// drains the ring at every stage.  As opaque asm it is left alone; the caller waits with lgkm_wait_tied() before
+// the first use of the fragments.
+__device__ __forceinline__ bf16x4 ds_read_tr_asm(const char* addr) {
+  bf16x4 v;
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)addr;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+
 // 16 rows x 32 k fragment of v_mfma_f32_16x16x32_bf16: lane l holds row (l&15), k = 8*(l>>4) + j
-template <bool TR, int ROWS>
+template <bool TR, int ROWS, bool ASM = false>
 __device__ __forceinline__ bf16x8 read_frag2(const char* tile, int row_base, int lane) {
   if (!TR) {
     const int row = row_base + (lane & 15);
@@ -83,7 +94,8 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* tile, int row_base, int
       const int krow = 8 * g + 4 * half + q;
       const int f = 2 * (krow & 3) + 8 * ((krow >> 3) & 1);
       const char* addr = tile + krow * (ROWS * 2) + (((col >> 3) ^ f) << 4) + ((col & 4) ? 8 : 0);
-      const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)addr);
+      const bf16x4 v = ASM ? ds_read_tr_asm(addr)
+                           : __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)addr);
       out[4 * half + 0] = v[0]; out[4 * half + 1] = v[1]; out[4 * half + 2] = v[2]; out[4 * half + 3] = v[3];
     }
     return out;
@@ -190,9 +202,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       const char* cur = lds + buf * STAGE;
       if ((DIAG & 2) == 0 || kt == 0) {
 #pragma unroll
-        for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<TB, BN>(cur + A_BYTES, wn * WTN + j * 16, lane);
+        for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<TB, BN, true>(cur + A_BYTES, wn * WTN + j * 16, lane);
 #pragma unroll
-        for (int i = 0; i < TMt; ++i) af[i] = read_frag2<TA, BM>(cur, wm * WTM + i * 16, lane);
+        for (int i = 0; i < TMt; ++i) af[i] = read_frag2<TA, BM, true>(cur, wm * WTM + i * 16, lane);
       }
       {
         // retire this wave's share of stage kt+1 (read by group 0 two slots from now)
@@ -206,6 +218,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- MFMA slot ----------------
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (TA || TB) {   // asm reads: the compiler does not know they are pending
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // volatile asm statements keep their order: every fragment is redefined AFTER the wait, so no MFMA can be
+        // scheduled above it
+#pragma unroll
+        for (int i = 0; i < TMt; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) asm volatile("" : "+v"(bfr[j]));
+      }
       if constexpr (!(DIAG & 4)) {
 #pragma unroll
         for (int i = 0; i < TMt; ++i)
@@ -465,6 +486,10 @@ static Plan make_plan(const nbest_gemm_args* a) {
   else if (ft == 1) { pl.bm = 128; pl.bn = 128; }
   else if (ft == 0 && !a->trans_a && !a->trans_b && a->N % 256 == 0 && ((a->M + 255) / 256) * (a->N / 256) >= 1024) {
     pl.bm = 256; pl.bn = 256;   // ping-pong schedule: best for k-contiguous operands on the wide GEMMs (QKV, FFN-up forward)
+  } else if (ft == 0 && a->trans_a && a->trans_b && a->epilogue == NBEST_EPI_F32_SPLITK && ok256 &&
+             (a->M / 256) * (a->N / 256) >= 18) {
+    pl.bm = 256; pl.bn = 256;   // weight gradients with >= 18 output tiles (QKV, FFN): 1.0-1.05 PFLOP/s vs 0.85-0.94 for v1;
+                                // the 768x768 attention-output gradient (9 tiles, 28 splits) stays on v1 (0.90 vs 0.79)
   }
   const int64_t tiles = ((a->M + pl.bm - 1) / pl.bm) * (a->N / pl.bn);
   const int64_t slots = (pl.bn == 256) ? 256 : 512;   // workgroups resident at once
