@@ -219,3 +219,47 @@ def test_too_long_sequence_fails_loudly(labels):
     ids = torch.randint(5, 2000, (1, 300), device="cuda")
     with pytest.raises(RuntimeError, match="S=300"):
         m.forward_backward(ids, torch.zeros(1, labels.n_bottom, device="cuda"))
+
+
+def test_training_step_is_hip_graph_capturable(labels):
+    """one whole step (forward, losses, backward, BertAdam) enqueues only kernels on the caller's stream - no allocation
+    through the driver, no host synchronisation - so it can be captured in a HIP graph; a replay produces the same
+    parameters as the eager step from the same state (dropout off)"""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    from nbest_amd.optim import HipBertAdam
+    from nbest_amd.trainer import train_step
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = synth.model_state(cfg, labels, seed=41)
+    b = synth.nbest_batch(cfg, labels, 4, 64, n_best=5, seed=7)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+
+    def fresh():
+        m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.bfloat16, dropout=0.0)
+        m.load_reference_state(sd)
+        m.train()
+        return m, HipBertAdam(m, lr=1e-3, bert_lr=1e-3, warmup=-1, t_total=-1)
+
+    m1, o1 = fresh()
+    train_step(m1, o1, batch)                      # eager: state after ONE step
+    torch.cuda.synchronize()
+    want = m1.arena.p.clone()
+
+    m2, o2 = fresh()
+    start = (m2.arena.p.clone(), m2.arena.w16.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                  # warm-up outside the capture: workspaces get allocated
+        train_step(m2, o2, batch)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        train_step(m2, o2, batch)
+    m2.arena.p.copy_(start[0]); m2.arena.w16.copy_(start[1])
+    m2.arena.refresh_transposed()
+    m2.arena.m.zero_(); m2.arena.v.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(m2.arena.p, want, rtol=0, atol=2e-6), (m2.arena.p - want).abs().max().item()
