@@ -115,6 +115,12 @@ __device__ __forceinline__ void wave_sum2(float& a, float& b) {
   a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
   a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
 }
+__device__ __forceinline__ float wave_sum_dpp(float a) {
+  a = dpp_add<0xB1>(a); a = dpp_add<0x4E>(a); a = dpp_add<0x141>(a); a = dpp_add<0x140>(a);
+  a += __shfl_xor(a, 16, 64);
+  a += __shfl_xor(a, 32, 64);
+  return a;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -59,6 +59,67 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
+// bf16 fast path of the LayerNorm forward (H == VPL*256): no bounds checks, gamma / beta in registers, the next row
+// in flight while this one is reduced, DPP reductions.  Two-pass variance as the generic kernel.
+__device__ __forceinline__ f32x2 unpack2(uint32_t w) {
+  return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+}
+__device__ __forceinline__ uint32_t pack2(f32x2 v) {
+  bf16x2 o;
+  o[0] = (bf16)v[0]; o[1] = (bf16)v[1];
+  return __builtin_bit_cast(uint32_t, o);
+}
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, bf16* __restrict__ y,
+                                                          float* __restrict__ stats, int64_t M, float eps) {
+  constexpr int H = VPL * 256;
+  constexpr float invH = 1.0f / (float)H;
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f32x2 gm[VPL][2], bt[VPL][2];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const f32x4 g4 = *(const f32x4*)(gamma + 4 * (lane + 64 * i)), b4 = *(const f32x4*)(beta + 4 * (lane + 64 * i));
+    gm[i][0] = f32x2{g4[0], g4[1]}; gm[i][1] = f32x2{g4[2], g4[3]};
+    bt[i][0] = f32x2{b4[0], b4[1]}; bt[i][1] = f32x2{b4[2], b4[3]};
+  }
+  uint2 nx[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) nx[i] = *(const uint2*)(x + row * H + 4 * (lane + 64 * i));
+  for (; row < M; row += stride) {
+    uint2 cx[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) cx[i] = nx[i];
+    const int64_t nrow = (row + stride < M) ? row + stride : row;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) nx[i] = *(const uint2*)(x + nrow * H + 4 * (lane + 64 * i));
+    f32x2 v[VPL][2];
+    f32x2 ps = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i][0] = unpack2(cx[i].x); v[i][1] = unpack2(cx[i].y);
+      ps += v[i][0]; ps += v[i][1];
+    }
+    const float mean = wave_sum_dpp(ps[0] + ps[1]) * invH;
+    f32x2 pq = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      v[i][0] = v[i][0] - mean; v[i][1] = v[i][1] - mean;
+      pq += v[i][0] * v[i][0]; pq += v[i][1] * v[i][1];
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(pq[0] + pq[1]) * invH + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const f32x2 o0 = v[i][0] * rstd * gm[i][0] + bt[i][0], o1 = v[i][1] * rstd * gm[i][1] + bt[i][1];
+      *(uint2*)(y + row * H + 4 * (lane + 64 * i)) = uint2{pack2(o0), pack2(o1)};
+    }
+    if (lane == 0) *(f32x2*)(stats + 2 * row) = f32x2{mean, rstd};
+  }
+}
+
 // partials layout: part[k][blk][H], k = 0 dgamma, 1 dbeta, 2 dbias(sum of dx)
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
@@ -171,14 +232,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // shuffles, six LDS-crossbar shuffles per reduction) and was VALU-issue bound at two waves per SIMD (59 us for 200 MB).
 // Here: packed-pair fp32 math, bf16 pairs unpacked with one shift / one mask, DPP reductions, the dropout hash input
 // formed by addition from a per-row scalar base, compile-time DROP / DBIAS, conflict-free LDS accumulation.
-__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) {
-  return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
-}
-__device__ __forceinline__ uint32_t pack_bf16x2(f32x2 v) {
-  bf16x2 o;
-  o[0] = (bf16)v[0]; o[1] = (bf16)v[1];
-  return __builtin_bit_cast(uint32_t, o);
-}
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) { return unpack2(w); }
+__device__ __forceinline__ uint32_t pack_bf16x2(f32x2 v) { return pack2(v); }
 
 template <int VPL, bool DROP, bool DBIAS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void ln_bwd_fast_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
@@ -595,11 +650,19 @@ extern "C" int nbest_layernorm_fwd(const void* x, const float* gamma, const floa
   if (int e = check_h(H)) return e;
   NB_CHECK(x && gamma && beta && y && stats && M > 0, NBEST_ERR_ARG, "layernorm_fwd: null pointer or M <= 0");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_rows(M, 4);
+  const int grid0 = grid_rows(M, 4);
   if (dtype == NBEST_F32) {
-    DISPATCH_VPL(H, (ln_fwd_kernel<float, VPL><<<grid, 256, 0, st>>>((const float*)x, gamma, beta, (float*)y, stats, M, H, eps)));
+    DISPATCH_VPL(H, (ln_fwd_kernel<float, VPL><<<grid0, 256, 0, st>>>((const float*)x, gamma, beta, (float*)y, stats, M, H, eps)));
+  } else if (dtype == NBEST_BF16 && H % 256 == 0 && H <= 1024) {
+    const int grid = grid0 < 1024 ? grid0 : 1024;   // 512 ... 4096 blocks tie at 17 us for 100 MB (5.9 TB/s); 8192: 19.5
+    switch (H / 256) {
+      case 1: ln_fwd_fast_kernel<1><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps); break;
+      case 2: ln_fwd_fast_kernel<2><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps); break;
+      case 3: ln_fwd_fast_kernel<3><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps); break;
+      default: ln_fwd_fast_kernel<4><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps); break;
+    }
   } else if (dtype == NBEST_BF16) {
-    DISPATCH_VPL(H, (ln_fwd_kernel<bf16, VPL><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, H, eps)));
+    DISPATCH_VPL(H, (ln_fwd_kernel<bf16, VPL><<<grid0, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, H, eps)));
   } else NB_CHECK(false, NBEST_ERR_DTYPE, "layernorm_fwd: bad dtype %d", dtype);
   NB_LAUNCH_CHECK();
   return NBEST_OK;
