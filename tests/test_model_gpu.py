@@ -263,3 +263,48 @@ def test_training_step_is_hip_graph_capturable(labels):
     g.replay()
     torch.cuda.synchronize()
     assert torch.allclose(m2.arena.p, want, rtol=0, atol=2e-6), (m2.arena.p - want).abs().max().item()
+
+
+def test_full_size_batch_additivity(labels):
+    """BASELINE configs[1] at FULL size (bert-base, 12 layers, 256 utterances x 128 tokens, bf16) through a
+    size-independent property: the reference's losses are sum-reduced, so loss and every gradient of the whole batch
+    equal the sums over its two halves.  The halves run different kernel plans (M = 16 384 vs 32 768 token rows:
+    other split-K factors, tile rounds and row-block counts), so this cross-checks the full-size launches."""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    cfg = ncfg.bert_base(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.bfloat16, dropout=0.0)
+    m.load_reference_state(synth.model_state(cfg, labels, seed=3))
+    m.train()
+    b = synth.nbest_batch(cfg, labels, 256, 128, n_best=5, seed=21, ragged=True)
+    t = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+
+    def run(lo, hi):
+        out = m.forward_backward(t["ids"][lo:hi].contiguous(), t["labels"][lo:hi].contiguous(), seg_ids=t["seg"][lo:hi].contiguous())
+        torch.cuda.synchronize()
+        return out["loss_parts"].double().sum().item(), m.arena.g.clone(), out["final"].clone()
+
+    lf, gf, ff = run(0, 256)
+    la, ga, fa = run(0, 128)
+    lb, gb, fb = run(128, 256)
+    assert torch.isfinite(gf).all() and gf.abs().max() > 0
+    assert abs(lf - (la + lb)) <= 2e-3 * abs(lf), (lf, la + lb)
+    assert torch.allclose(ff, torch.cat([fa, fb]), rtol=0, atol=2e-2)         # per-utterance scores do not depend on the batch
+    gs = ga + gb
+    a = m.arena
+    for name in ("bert_encoder.encoder.layer.0.attention.self.query.weight", "bert_encoder.encoder.layer.5.intermediate.dense.weight",
+                 "bert_encoder.encoder.layer.11.output.dense.weight", "bert_encoder.encoder.layer.7.attention.output.LayerNorm.weight",
+                 "bert_encoder.embeddings.word_embeddings.weight", "clf.top_lin.weight" if "clf.top_lin.weight" in a.by_name else a.slots[-2].name):
+        s = a.by_name[name]
+        x, y = gf[s.offset:s.offset + s.numel], gs[s.offset:s.offset + s.numel]
+        rel = (x - y).norm().item() / max(y.norm().item(), 1e-12)
+        assert rel < 2e-2, (name, rel)
+    rel_all = (gf - gs).norm().item() / gs.norm().item()
+    assert rel_all < 2e-2, rel_all
+    # run-to-run determinism at full size: every encoder-layer and head gradient is bit-identical (split-K slabs are
+    # reduced in split order, column sums through partial rows); only the embedding tables use float atomics
+    _, gf2, _ = run(0, 256)
+    lo, hi = a.layer_range[0][0], a.layer_range[-1][1]
+    assert torch.equal(gf[lo:hi], gf2[lo:hi])
+    assert torch.equal(gf[a.heads_range[0]:a.heads_range[1]], gf2[a.heads_range[0]:a.heads_range[1]])
