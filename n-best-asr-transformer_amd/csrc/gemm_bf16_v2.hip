@@ -114,9 +114,14 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else static_assert(N < 0, "add the literal");
 }
 
+#define NB_STAMP(IDX)                                                                                          \
+  if ((DIAG & 32) && p.U && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 700))                       \
+    ((uint64_t*)p.U)[16000 + (blockIdx.x ? 8 : 0) + (IDX)] = __builtin_readcyclecounter()
+
 template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  NB_STAMP(0);
   constexpr int NT = WM * WN * 64;                   // 256 threads (2 x 2 waves) or 512 (2 x 4 waves)
   constexpr bool PIPE = (BM == 128 && NT == 256);   // second fragment register set: fits only the 64x64 wave tile
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }
     __builtin_amdgcn_s_barrier();                 // stage 0 landed for everyone
     asm volatile("" ::: "memory");
+    NB_STAMP(1);
     if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
     int buf = 0;
     bf16x8 af[TMt], bfr[TNt];
@@ -214,7 +220,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         else if (c == 1) wait_vm<0>();
       }
       __builtin_amdgcn_sched_barrier(0);
+      if ((DIAG & 32) && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && p.U) ((uint64_t*)p.U)[(wave >> 2) * 8192 + 4 * kt + 0] = __builtin_readcyclecounter();
       __builtin_amdgcn_s_barrier();
+      if ((DIAG & 32) && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && p.U) ((uint64_t*)p.U)[(wave >> 2) * 8192 + 4 * kt + 1] = __builtin_readcyclecounter();
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- MFMA slot ----------------
       __builtin_amdgcn_s_setprio(1);
@@ -240,11 +248,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      if ((DIAG & 32) && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && p.U) ((uint64_t*)p.U)[(wave >> 2) * 8192 + 4 * kt + 2] = __builtin_readcyclecounter();
       __builtin_amdgcn_s_barrier();
+      if ((DIAG & 32) && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && p.U) ((uint64_t*)p.U)[(wave >> 2) * 8192 + 4 * kt + 3] = __builtin_readcyclecounter();
       __builtin_amdgcn_sched_barrier(0);
       buf = (buf + 1 == STAGES) ? 0 : buf + 1;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count
+    NB_STAMP(2);
   } else if constexpr (PIPE) {
   // ---- ring: buffers hold stages kt+1 .. kt+STAGES; fragments of stage kt+1 are read (into the other
   // register set) while the MFMAs of stage kt run, so no LDS round trip is exposed at a stage boundary.
@@ -426,6 +437,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }
     asm volatile("" ::: "memory");
   }
+  if (DIAG & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stamp after the stores are acknowledged
+  NB_STAMP(3);
   if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {   // fused bias gradient: per-wave column sums -> partial rows
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
