@@ -103,15 +103,8 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* tile, int row_base, int
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else static_assert(N < 0, "add the literal");
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 #define NB_STAMP(IDX)                                                                                          \
@@ -454,6 +447,197 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   }
 }
 
+// LDS / global accesses that the wait-count pass must not see (it would drain the in-flight LDS-DMA ring, and every
+// store with it, in front of each of them); the caller orders them with explicit s_waitcnt.
+__device__ __forceinline__ void lds_write_b128_asm(const void* addr, f32x4 v) {
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)addr;
+  asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 lds_read_b128_asm(const void* addr) {
+  f32x4 v;
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)addr;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+__device__ __forceinline__ f32x4 global_load_f32x4_asm(const float* ptr) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+  return v;
+}
+
+// ---- persistent ping-pong kernel -------------------------------------------------------------------------------
+// One workgroup per CU walks tiles b, b+G, b+2G, ...; the 4-stage LDS ring simply runs on into the next tile: the
+// last three LOAD slots of a tile issue stages 0..2 of the NEXT tile, so its prologue (≈10 % of a K = 768 tile,
+// the LDS-DMA latency of the first stage) is hidden behind the current tile's MFMAs and epilogue.  While those
+// three stages sit in three ring buffers the epilogue restages through the fourth (32 KiB: 4 KiB per wave, 16-row
+// chunks).  k-contiguous operands, epilogues without a residual / GELU' input (NONE, BIAS, BIAS_GELU), splits == 1,
+// nk >= 3.  vmcnt: the epilogue's stores (and the tile's bias loads) enter the per-wave stream between DMA stages;
+// completion is in order, so the counted waits of the first two LOAD slots of a tile allow for them explicitly
+// (full tiles issue a fixed number of stores; the ragged last row tile drains with vmcnt(0) instead).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int BM = 256, BN = 256, WN = 4, NT = 512, STAGES = 4;
+  constexpr int WTM = 128, WTN = 64, TMt = 8, TNt = 4;
+  constexpr int A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES;
+  constexpr int NDMA = (BM + BN) * 4 / NT;   // 4
+  constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU);
+  constexpr int NSTORE = (WTM / 8) * (EPI == NBEST_EPI_BIAS_GELU ? 2 : 1);   // store instructions per wave and (full) tile
+  constexpr int NBIAS = kHasBias ? 2 : 0;
+  static_assert(EPI == NBEST_EPI_NONE || EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU, "no residual / GELU' input");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int grp = __builtin_amdgcn_readfirstlane(wm);
+  const int G = gridDim.x, tiles = p.tiles_m * p.tiles_n;
+  const int nk = (int)(p.K / BK);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+
+  auto tile_origin = [&](int t, int64_t& m0, int64_t& n0) {
+    const int id = xcd_remap2(t, tiles);
+    const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+    m0 = (int64_t)tile_m * BM; n0 = (int64_t)tile_n * BN;
+  };
+  auto issue = [&](int gstage, int64_t m0, int64_t n0, int s) {   // stage s of the tile at (m0, n0) -> ring buffer gstage & 3
+    char* dst = lds + (gstage & 3) * STAGE;
+    stage_tile2<false, BM, NT>(rsA, dst, m0, (int64_t)s * BK, p.lda, tid);
+    stage_tile2<false, BN, NT>(rsB, dst + A_BYTES, n0, (int64_t)s * BK, p.ldb, tid);
+  };
+
+  int t_cur = blockIdx.x;
+  int64_t m0, n0;
+  tile_origin(t_cur, m0, n0);
+  int gs = 0;   // ring position of stage 0 of the current tile
+#pragma unroll
+  for (int s = 0; s < 3; ++s) issue(gs + s, m0, n0, s);
+  int dbg_i = 0;
+#define NB_PSTAMP() if ((DIAG & 32) && EPI == NBEST_EPI_NONE && p.U && tid == 0 && blockIdx.x == 0 && dbg_i < 64) ((uint64_t*)p.U)[dbg_i++] = __builtin_readcyclecounter()
+  NB_PSTAMP();
+  if ((DIAG & 32) && EPI == NBEST_EPI_NONE && p.U && tid == 0) ((uint64_t*)p.U)[1000 + 2 * blockIdx.x] = __builtin_readcyclecounter();
+  int extra = 0;   // younger non-DMA operations (stores of the previous tile, bias loads) that may precede stage 3 in the stream
+
+  while (true) {
+    const int t_next = t_cur + G;
+    const bool has_next = t_next < tiles;
+    int64_t m0n = 0, n0n = 0;
+    if (has_next) tile_origin(t_next, m0n, n0n);
+    const int64_t en8 = n0 + wn * WTN + (lane & 7) * 8;
+    f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
+    if (kHasBias) { pb0 = global_load_f32x4_asm(p.bias + en8); pb1 = global_load_f32x4_asm(p.bias + en8 + 4); }
+    f32x4 acc[TMt][TNt];
+#pragma unroll
+    for (int i = 0; i < TMt; ++i)
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    // stage 0 landed: stream tail is  s0 s1 s2 [stores of the previous tile] [bias loads]
+    if (extra < 0) wait_vm<0>();
+    else if (extra == 0) wait_vm<2 * NDMA + NBIAS>();   // first tile of this workgroup: no stores in the stream yet
+    else wait_vm<2 * NDMA + NSTORE + NBIAS>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    NB_PSTAMP();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
+    bf16x8 af[TMt], bfr[TNt];
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---------------- LOAD slot ----------------
+      const int si = kt + 3;
+      if (si < nk) issue(gs + si, m0, n0, si);
+      else if (has_next) issue(gs + si, m0n, n0n, si - nk);
+      const char* cur = lds + ((gs + kt) & 3) * STAGE;
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<false, BN>(cur + A_BYTES, wn * WTN + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < TMt; ++i) af[i] = read_frag2<false, BM>(cur, wm * WTM + i * 16, lane);
+      {
+        // stage kt+1 must have landed; younger: the stages issued after it (+ at kt = 0, 1 the non-DMA operations
+        // that sit between stage 2 and stage 3 of this tile in the stream)
+        const int c = has_next ? 3 : ((nk - 1 - kt < 3) ? nk - 1 - kt : 3);   // stages kt+1 .. outstanding
+        if (c >= 3) {
+          if (kt >= 2) wait_vm<2 * NDMA>();
+          else if (extra < 0) wait_vm<0>();
+          else if (extra == 0) wait_vm<2 * NDMA + NBIAS>();
+          else wait_vm<2 * NDMA + NSTORE + NBIAS>();
+        } else if (c == 2) wait_vm<NDMA>();   // (with nk < 5 this over-waits for the mixed operations at kt < 2: safe)
+        else wait_vm<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- MFMA slot ----------------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TMt; ++i)
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count: both groups are in step again
+    NB_PSTAMP();
+
+    // ---- epilogue: 16-row chunks through the one ring buffer the next tile's first three stages do not occupy ----
+    float* ep = (float*)(lds + ((gs + nk + 3) & 3) * STAGE) + wave * 1024;
+    const bool full = (m0 + BM <= p.M);
+    // the bias loads of this tile are older than its stage 3, and stage nk-1 has landed (in-order completion)
+    if (kHasBias) asm volatile("" : "+v"(pb0), "+v"(pb1));
+#pragma unroll
+    for (int c = 0; c < TMt; ++c) {
+      const int wrow = lane & 15;
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) {
+        const int cidx = j * 4 + (lane >> 4);
+        lds_write_b128_asm(ep + wrow * 64 + ((cidx ^ wrow) << 2), acc[c][j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      f32x4 rv[2][2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int pidx = it * 64 + lane, row = pidx >> 3, c8 = pidx & 7;
+        rv[it][0] = lds_read_b128_asm(ep + row * 64 + (((2 * c8) ^ row) << 2));
+        rv[it][1] = lds_read_b128_asm(ep + row * 64 + (((2 * c8 + 1) ^ row) << 2));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(rv[0][0]), "+v"(rv[0][1]), "+v"(rv[1][0]), "+v"(rv[1][1]));
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int pidx = it * 64 + lane, row = pidx >> 3;
+        const int64_t m = m0 + wm * WTM + c * 16 + row;
+        const f32x4 v0 = rv[it][0], v1 = rv[it][1];
+        if (m >= p.M) continue;
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (kHasBias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += pb0[e]; v[4 + e] += pb1[e]; }
+        }
+        if (EPI == NBEST_EPI_BIAS_GELU) {
+          float gp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float cdf, ex;
+            gelu_parts_fast(v[e], cdf, ex);
+            gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
+            v[e] *= cdf;
+          }
+          Vec8<bf16>::store(p.U + m * p.ldu + en8, gp);
+        }
+        Vec8<bf16>::store((bf16*)p.C + m * p.ldc + en8, v);
+      }
+      asm volatile("" ::: "memory");
+    }
+    NB_PSTAMP();
+    if ((DIAG & 32) && EPI == NBEST_EPI_NONE && p.U && tid == 0 && !has_next) ((uint64_t*)p.U)[1001 + 2 * blockIdx.x] = __builtin_readcyclecounter();
+    if (!has_next) break;
+    __builtin_amdgcn_s_barrier();   // every wave is done with the restage buffer: stage 3 of the next tile may overwrite it
+    asm volatile("" ::: "memory");
+    extra = full ? NSTORE : -1;      // ragged tile: unknown store count -> the next tile drains with vmcnt(0)
+    gs += nk;
+    t_cur = t_next; m0 = m0n; n0 = n0n;
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float* __restrict__ slab, float* __restrict__ C, int64_t MN,
                                                              int64_t N, int64_t ldc, int splits, int accumulate) {
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * blockDim.x * 4) {
@@ -470,6 +654,11 @@ struct Plan {
   int bm, bn, splits;
   int64_t kps;
 };
+
+static bool persistent_enabled() {
+  static const bool v = [] { const char* e = getenv("NBEST_PERSISTENT"); return e && *e == '1'; }();
+  return v;
+}
 
 // NBEST_TILE=256x256 | 256x128 | 128x128 forces a tile (experiments); default: per-shape choice
 static int forced_tile() {
@@ -609,6 +798,20 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
     if (!a->trans_a && !a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, true>(p, epi, grid, st);
     else rc = launch2<128, 256, 2, 4, 4, true, true>(p, epi, grid, st);
+  } else if (pl.bm == 256 && pl.bn == 256 && !a->trans_a && !a->trans_b && pl.splits == 1 && !p.colpart && a->K % BK == 0 &&
+             a->K >= 3 * BK && grid > 256 && (epi == NBEST_EPI_NONE || epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU) &&
+             persistent_enabled()) {
+    constexpr int lds_bytes = 4 * 2 * 256 * BK * 2;
+    const int pgrid = 256;
+#define LP(E)                                                                                              \
+  case E:                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)gemm2p_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    gemm2p_kernel<E><<<pgrid, 512, lds_bytes, st>>>(p);                                                    \
+    break;
+    switch (epi) { LP(NBEST_EPI_NONE) LP(NBEST_EPI_BIAS) LP(NBEST_EPI_BIAS_GELU) default: break; }
+#undef LP
+    NB_LAUNCH_CHECK();
+    rc = NBEST_OK;
   } else if (pl.bm == 256 && pl.bn == 256) {
     if (!a->trans_a && !a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, true>(p, epi, grid, st);
