@@ -680,7 +680,7 @@ extern "C" int nbest_layernorm_bwd(const void* dy, const void* x, const float* s
   NB_CHECK(M * (int64_t)H < (int64_t)1 << 32 || d.thr16 == 0, NBEST_ERR_SHAPE, "layernorm_bwd: dropout counter overflow");
   hipStream_t st = (hipStream_t)stream;
   int nblk = (int)((M + 31) / 32 < 1 ? 1 : ((M + 31) / 32 > kMaxLnBwdBlocks ? kMaxLnBwdBlocks : (M + 31) / 32));
-  if (nblk > 256) nblk = 256;   // measured: 256 and 512 blocks tie (32 us for 200 MB); fewer partial rows = shorter finalize (7.4 vs 9.4 us)
+  if (nblk > 512) nblk = 512;   // isolated, 256 and 512 blocks tie (32 us for 200 MB); inside the step 512 is faster (35 vs 44 us)
   int rpb = (int)((M + nblk - 1) / nblk);
   nblk = (int)((M + rpb - 1) / rpb);
   constexpr int waves = 4;
