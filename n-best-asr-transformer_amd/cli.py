@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import config as ncfg, observe, synth, trainer
-from .inputs import WordPieceTokenizer
+from .inputs import SentencePieceTokenizer, WordPieceTokenizer
 from .model import NBestSTCModel
 from .optim import HipBertAdam
 
@@ -124,8 +124,11 @@ def load_memory(opt):
 
 
 def load_tokenizer(opt, memory):
-    if not opt.vocab and opt.pretrained_path and os.path.exists(os.path.join(opt.pretrained_path, "vocab.txt")):
-        opt.vocab = os.path.join(opt.pretrained_path, "vocab.txt")
+    for fn in ("vocab.txt", "sentencepiece.bpe.model"):
+        if not opt.vocab and opt.pretrained_path and os.path.exists(os.path.join(opt.pretrained_path, fn)):
+            opt.vocab = os.path.join(opt.pretrained_path, fn)
+    if opt.vocab and opt.vocab.endswith(".model"):              # sentencepiece model (XLM-R family)
+        return SentencePieceTokenizer(opt.vocab)
     if opt.vocab:
         if opt.vocab.endswith(".json"):
             vocab = json.load(open(opt.vocab))
@@ -165,9 +168,8 @@ def main(argv=None):
     cfg = ncfg.NAMED[family](hidden_dropout_prob=opt.bert_dropout, attention_probs_dropout_prob=opt.bert_dropout)
     if opt.encoder_layers:
         cfg.num_hidden_layers = opt.encoder_layers
-    if family == "bert":
-        if opt.vocab or not (opt.init_checkpoint or opt.pretrained_path):
-            cfg.vocab_size = max(opt.tokenizer.vocab_size, 8)
+    if (family == "bert" and not (opt.init_checkpoint or opt.pretrained_path)) or opt.vocab:
+        cfg.vocab_size = max(opt.tokenizer.vocab_size, 8)          # embedding table sized for the local vocabulary
     model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=torch.bfloat16 if opt.dtype == "bf16" else torch.float32,
                           dropout=opt.dropout, seed=opt.random_seed)
     if opt.init_checkpoint:

@@ -92,6 +92,50 @@ class WordPieceTokenizer:
         return [self.vocab.get(t, unk) for t in toks]
 
 
+class SentencePieceTokenizer:
+    """XLM-R style tokenizer over a LOCAL sentencepiece model (no network): the id convention of
+    ``XLMRobertaTokenizer`` — ``<s>``=0, ``<pad>``=1, ``</s>``=2, ``<unk>``=3, every sentencepiece id shifted by +1
+    (fairseq offset), ``<mask>`` last — behind the interface the input builder uses."""
+
+    def __init__(self, model_file):
+        import re
+        import sentencepiece as spm
+        self.sp = spm.SentencePieceProcessor(model_file=model_file)
+        self.cls_token, self.sep_token, self.pad_token, self.unk_token = "<s>", "</s>", "<pad>", "<unk>"
+        self.special_ids = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+        self.pad_token_id = 1
+        self._mask_id = self.sp.get_piece_size() + 1
+        self._split = re.compile("(<s>|</s>|<pad>|<unk>|<mask>)")
+        self._cache = {}
+
+    @property
+    def vocab_size(self):
+        return self.sp.get_piece_size() + 2
+
+    def tokenize(self, word):
+        hit = self._cache.get(word)
+        if hit is None:
+            hit = []
+            for part in self._split.split(word):           # "</s></s>" -> two separator tokens
+                if not part:
+                    continue
+                hit += [part] if self._split.fullmatch(part) else self.sp.encode(part, out_type=str)
+            self._cache[word] = hit
+        return list(hit)
+
+    def convert_tokens_to_ids(self, toks):
+        out = []
+        for t in toks:
+            if t in self.special_ids:
+                out.append(self.special_ids[t])
+            elif t == "<mask>":
+                out.append(self._mask_id)
+            else:
+                i = self.sp.piece_to_id(t)
+                out.append(3 if i == self.sp.unk_id() else i + 1)
+        return out
+
+
 def cut_n_best(seq, n_best):
     """keep the first n hypotheses of ``.. [USR] h1 [SEP] h2 [SEP] ..`` (build extension; reference data has <= 10)"""
     if not n_best:

@@ -201,3 +201,35 @@ def test_encoded_split_and_prefetcher_match_per_batch_builder(labels):
     full, _ = inputs.encode_utterance(data[0][0], tok, opt)
     cut, seg = inputs.encode_utterance(data[0][0], tok, opt, max_seq_len=20)
     assert len(full) > 20 and len(cut) == 20 and cut[:19] == full[:19] and cut[-1] == vocab.index("[SEP]") and len(seg) == 20
+
+
+def test_sentencepiece_tokenizer_xlmr_layout(tmp_path):
+    """XLM-R input layout from a LOCAL sentencepiece model: <s> sys.. </s></s> hyp1 </s></s> hyp2 </s>, fairseq id offset,
+    pad id 1, unknown pieces -> 3 (bert_xlnet_inputs.py:37-43 doubled separator; XLMRobertaTokenizer id convention)"""
+    import sentencepiece as spm
+    text = tmp_path / "corpus.txt"
+    lines = open(os.path.join(GOLDEN, "valid_head.txt")).read().replace("\t<=>\t", " ").replace("[", " ").replace("]", " ")
+    text.write_text(lines)
+    spm.SentencePieceTrainer.train(input=str(text), model_prefix=str(tmp_path / "sp"), vocab_size=120, model_type="unigram",
+                                   minloglevel=2)
+    tok = inputs.SentencePieceTokenizer(str(tmp_path / "sp.model"))
+    assert (tok.cls_token, tok.sep_token, tok.pad_token_id) == ("<s>", "</s>", 1) and tok.vocab_size == 122
+    assert tok.tokenize("</s></s>") == ["</s>", "</s>"]
+    pieces = tok.tokenize("restaurant")
+    ids = tok.convert_tokens_to_ids(pieces)
+    assert pieces[0].startswith("▁") and all(i >= 4 for i in ids)
+    assert ids == [tok.sp.piece_to_id(p) + 1 for p in pieces]
+    assert tok.convert_tokens_to_ids(["<s>", "<pad>", "</s>", "<unk>", "▁zzzzqq"]) == [0, 1, 2, 3, 3]
+    opt = type("O", (), dict(pre_trained_model="xlm-roberta"))()
+    seq = "[CLS] [SYS] hello there [USR] cheap food [SEP] cheap foot".split(" ")
+    ids, seg = inputs.encode_utterance(seq, tok, opt)
+    # reference quirk (bert_xlnet_inputs.py:40,78): the FIRST separator enters the token list as the single string
+    # "</s></s>", which is not a vocabulary entry -> <unk>; the separators between hypotheses are tokenised -> </s> </s>
+    toks = ["<s>"] + tok.tokenize("hello") + tok.tokenize("there") + ["</s></s>"] + tok.tokenize("cheap") + tok.tokenize("food") + \
+        ["</s>", "</s>"] + tok.tokenize("cheap") + tok.tokenize("foot") + ["</s>"]
+    assert ids == tok.convert_tokens_to_ids(toks) and ids[0] == 0 and ids[-1] == 2
+    assert ids[1 + len(tok.tokenize("hello")) + len(tok.tokenize("there"))] == 3
+    n_a = 1 + len(tok.tokenize("hello")) + len(tok.tokenize("there"))
+    assert seg == [0] * n_a + [1] * (len(ids) - n_a)
+    batch_ids, _, lens = inputs.collate([(ids, seg), (ids[:5], seg[:5])], tok.pad_token_id)
+    assert batch_ids[1, 5:].eq(1).all() and lens == [len(ids), 5]
