@@ -111,6 +111,7 @@ def main():
     run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim)
     run_coverage_case()
     run_observe_case()
+    run_xlmr_input_case()
 
 
 def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
@@ -409,8 +410,43 @@ def run_observe_case():
                        ontology=onto, onto_labels=labs, onto_filtered=flt), f)
 
 
+def run_xlmr_input_case():
+    """XLM-R input layout: the reference's prepare_inputs_for_roberta (utils/bert_xlnet_inputs.py) driven with this
+    build's SentencePieceTokenizer over a tiny local sentencepiece model (trained here on the valid text, committed as
+    sp_tiny.model) -> ids / segment ids / lengths for the first 8 valid lines, with and without --without_system_act."""
+    import io, contextlib
+    import sentencepiece as spm
+    import utils.bert_xlnet_inputs as ref_inputs
+    import utils.dataset.tod_asr_util as ref_data
+    from nbest_amd import inputs
+    src = os.path.join(REF, "dstc2_data/processed_data/raw/valid")
+    with contextlib.redirect_stdout(io.StringIO()):
+        asr, _, _ = ref_data.read_wcn_data(src, 1.0)
+    asr = [[str(w) for w in a] for a in asr[:8]]
+    corpus = os.path.join(HERE, "_sp_corpus.txt")
+    with open(corpus, "w") as f:
+        f.write("\n".join(" ".join(w for w in a if not w.startswith("[")) for a in asr))
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(HERE, "sp_tiny"), vocab_size=90, model_type="unigram",
+                                   minloglevel=2)
+    os.remove(corpus)
+    os.remove(os.path.join(HERE, "sp_tiny.vocab"))
+    tok = inputs.SentencePieceTokenizer(os.path.join(HERE, "sp_tiny.model"))
+    out = {}
+    for name, no_sys in (("default", False), ("without_system_act", True)):
+        opt = types.SimpleNamespace(pre_trained_model="xlm-roberta", tod_pre_trained_model=None, without_system_act=no_sys)
+        ids, seg, lens = ref_inputs.prepare_inputs_for_roberta(asr, tok, opt, device="cpu")
+        mids, mseg, mlens = inputs.prepare_inputs_for_roberta(asr, tok, opt, "cpu")
+        assert torch.equal(ids, mids) and lens == mlens and ((seg is None and mseg is None) or torch.equal(seg, mseg)), name
+        out[name] = dict(ids=ids.tolist(), seg=None if seg is None else seg.tolist(), lens=lens)
+        print("   xlm-r input layout (%s): %d x %d identical to the reference's builder" % (name, ids.shape[0], ids.shape[1]))
+    with open(os.path.join(HERE, "xlmr_inputs.json"), "w") as f:
+        json.dump(dict(raw=[" ".join(a) for a in asr], **out), f)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["observe"]:
+    if sys.argv[1:] == ["xlmr"]:
+        run_xlmr_input_case()
+    elif sys.argv[1:] == ["observe"]:
         run_observe_case()
     else:
         main()

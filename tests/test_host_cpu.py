@@ -233,3 +233,16 @@ def test_sentencepiece_tokenizer_xlmr_layout(tmp_path):
     assert seg == [0] * n_a + [1] * (len(ids) - n_a)
     batch_ids, _, lens = inputs.collate([(ids, seg), (ids[:5], seg[:5])], tok.pad_token_id)
     assert batch_ids[1, 5:].eq(1).all() and lens == [len(ids), 5]
+
+
+def test_xlmr_input_builder_matches_reference_fixture():
+    """ids / segment ids / lengths the REFERENCE's prepare_inputs_for_roberta produced (make_golden.py xlmr) for the first 8
+    valid lines in xlm-roberta mode, with and without --without_system_act, over the committed tiny sentencepiece model"""
+    d = json.load(open(os.path.join(GOLDEN, "xlmr_inputs.json")))
+    tok = inputs.SentencePieceTokenizer(os.path.join(GOLDEN, "sp_tiny.model"))
+    raw = [r.split(" ") for r in d["raw"]]
+    for name, no_sys in (("default", False), ("without_system_act", True)):
+        opt = type("O", (), dict(pre_trained_model="xlm-roberta", tod_pre_trained_model=None, without_system_act=no_sys))()
+        ids, seg, lens = inputs.prepare_inputs_for_roberta(raw, tok, opt, "cpu")
+        assert ids.tolist() == d[name]["ids"] and lens == d[name]["lens"]
+        assert (seg is None and d[name]["seg"] is None) or seg.tolist() == d[name]["seg"]
