@@ -120,3 +120,25 @@ def test_local_hf_checkpoint_loads(tmp_path, labels):
     save_file(bad, str(ck / "model.safetensors"))
     with pytest.raises(RuntimeError, match="lacks encoder tensors"):
         m.load_pretrained_encoder(str(ck))
+
+
+def test_cli_xlm_roberta_with_local_sentencepiece(tmp_path):
+    """the XLM-R family end to end through the CLI: sentencepiece ids, pad id 1, <s> = 0 under the ids > 0 mask quirk,
+    pad-offset position ids, one token type"""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import cli
+    root = tmp_path / "data"
+    root.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "valid_head.txt"), root / "train")
+    shutil.copy(os.path.join(GOLDEN, "valid_head.txt"), root / "valid")
+    args = ["--dataset", "dstc2", "--dataroot", str(root), "--deviceId", "0", "--dropout", "0.3", "--bert_dropout", "0.1", "--lr", "3e-5",
+            "--bert_lr", "3e-5", "--batchSize", "8", "--max_epoch", "1", "--experiment", str(tmp_path / "exp"),
+            "--pre_trained_model", "xlm-roberta", "--add_segment_ids", "--add_l2_loss", "--n_best", "3",
+            "--label_space", os.path.join(GOLDEN, "label_space.json"), "--vocab", os.path.join(GOLDEN, "sp_tiny.model"),
+            "--encoder_layers", "2"]
+    assert cli.main(args) == 0
+    d = cli.exp_dir(cli.parse_arguments(args))
+    log = open(os.path.join(d, "log.train")).read()
+    assert "[Train]\tEpoch: 00" in log and "[Valid]\tEpoch: 00" in log and "nan" not in log.lower()
+    lines = open(os.path.join(d, "valid.iter0")).read().strip("\n").split("\n")
+    assert len(lines) == 24
