@@ -25,3 +25,4 @@ print("all workgroups: first start %d, last start +%d, first end +%d, last end +
     0, st.max() - st.min(), en.min() - st.min(), en.max() - st.min(), (en - st).min(), int(np.median(en - st)), (en - st).max()))
 slow = np.argsort(en - st)[-8:]
 print("slowest workgroups:", [(int(b), int((en - st)[b])) for b in slow])
+
