@@ -112,6 +112,7 @@ def main():
     run_coverage_case()
     run_observe_case()
     run_xlmr_input_case()
+    run_tod_input_case()
 
 
 def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
@@ -443,8 +444,30 @@ def run_xlmr_input_case():
         json.dump(dict(raw=[" ".join(a) for a in asr], **out), f)
 
 
+def run_tod_input_case():
+    """--tod_pre_trained_model layout ([CLS] [SYS] sys.. [USR] hyp1 [SEP] .. [SEP], segment ids on) from the reference's
+    builder over the committed WordPiece vocabulary, first 8 lines of valid_head.txt (ASR and transcript sides)."""
+    import utils.bert_xlnet_inputs as ref_inputs
+    from nbest_amd import inputs, trainer
+    vocab = json.load(open(os.path.join(HERE, "text_vocab.json")))
+    tok = inputs.WordPieceTokenizer(vocab)
+    data = trainer.read_wcn_data(os.path.join(HERE, "valid_head.txt"))
+    opt = types.SimpleNamespace(pre_trained_model="bert", tod_pre_trained_model="tod-bert", without_system_act=False)
+    out = {}
+    for name, side in (("asr", data[0][:8]), ("trans", data[1][:8])):
+        ids, seg, lens = ref_inputs.prepare_inputs_for_roberta(list(side), tok, opt, "cpu")
+        mids, mseg, mlens = inputs.prepare_inputs_for_roberta(list(side), tok, opt, "cpu")
+        assert torch.equal(ids, mids) and torch.equal(seg, mseg) and lens == mlens, name
+        out[name] = dict(ids=ids.tolist(), seg=seg.tolist(), lens=lens)
+    with open(os.path.join(HERE, "tod_inputs.json"), "w") as f:
+        json.dump(out, f)
+    print("   --tod_pre_trained_model input layout identical to the reference's builder (8 ASR + 8 transcript sequences)")
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["xlmr"]:
+    if sys.argv[1:] == ["tod"]:
+        run_tod_input_case()
+    elif sys.argv[1:] == ["xlmr"]:
         run_xlmr_input_case()
     elif sys.argv[1:] == ["observe"]:
         run_observe_case()

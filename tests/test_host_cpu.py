@@ -246,3 +246,16 @@ def test_xlmr_input_builder_matches_reference_fixture():
         ids, seg, lens = inputs.prepare_inputs_for_roberta(raw, tok, opt, "cpu")
         assert ids.tolist() == d[name]["ids"] and lens == d[name]["lens"]
         assert (seg is None and d[name]["seg"] is None) or seg.tolist() == d[name]["seg"]
+
+
+def test_tod_mode_input_builder_matches_reference_fixture():
+    """--tod_pre_trained_model keeps the [SYS] / [USR] markers (bert_xlnet_inputs.py:30-35, 55-65): ids / segment ids /
+    lengths the reference's builder produced (make_golden.py tod)"""
+    from nbest_amd import trainer
+    d = json.load(open(os.path.join(GOLDEN, "tod_inputs.json")))
+    tok = inputs.WordPieceTokenizer(json.load(open(os.path.join(GOLDEN, "text_vocab.json"))))
+    data = trainer.read_wcn_data(os.path.join(GOLDEN, "valid_head.txt"))
+    opt = type("O", (), dict(pre_trained_model="bert", tod_pre_trained_model="tod-bert", without_system_act=False))()
+    for name, side in (("asr", data[0][:8]), ("trans", data[1][:8])):
+        ids, seg, lens = inputs.prepare_inputs_for_roberta(side, tok, opt, "cpu")
+        assert ids.tolist() == d[name]["ids"] and seg.tolist() == d[name]["seg"] and lens == d[name]["lens"]
