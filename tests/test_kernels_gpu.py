@@ -225,11 +225,13 @@ def test_attention_fwd_bf16_long(S):
     close("attn_fwd bf16 lse S=%d" % S, lse, lse_ref, 1e-2)
 
 
-def test_attention_dropout_fwd_bwd_consistent():
+@pytest.mark.parametrize("S", [64, 37, 160])
+def test_attention_dropout_fwd_bwd_consistent(S):
     """bf16 MFMA and fp32 VALU kernels must draw the SAME mask from (seed, stream); the backward of
     each must be the gradient of its own forward (checked through the fp32 kernel by finite differences
-    on a linear functional)."""
-    B, S, heads, p = 2, 64, 2, 0.2
+    on a linear functional).  S = 64: one hash per key pair in the bf16 forward; S = 37 (odd): the per-element
+    fallback; S = 160: the five-block backward."""
+    B, heads, p = 2, 2, 0.2
     H = heads * 64
     qkv32 = rnd(B * S, 3 * H, seed=71)
     mask = torch.ones(B, S, dtype=torch.uint8, device=DEV)
