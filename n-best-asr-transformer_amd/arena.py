@@ -169,13 +169,16 @@ class ParamArena:
         return missing
 
     # ---- optimizer descriptors -----------------------------------------------------------------
-    def build_descs(self, lr, bert_lr, active=None):
-        """device array of nbest_tensor_desc, one per tensor (grouping of n_best_asr_bert.py:540-550)."""
+    def build_descs(self, lr, bert_lr, active=None, select=None):
+        """device array of nbest_tensor_desc, one per tensor (grouping of n_best_asr_bert.py:540-550);
+        ``select(name)`` restricts the set to some tensors (the optimizer is split so the embedding tables can be
+        updated after their own, last, gradient exchange)."""
         chunk = hb.lib().nbest_bertadam_chunk()
-        n = len(self.slots)
-        arr = (hb.TensorDesc * n)()
+        slots = [s for s in self.slots if select is None or select(s.name)]
+        n = len(slots)
+        arr = (hb.TensorDesc * max(n, 1))()
         blk = 0
-        for i, s in enumerate(self.slots):
+        for i, s in enumerate(slots):
             d = arr[i]
             d.offset, d.numel = s.offset, s.numel
             d.lr = bert_lr if "bert_encoder" in s.name else lr

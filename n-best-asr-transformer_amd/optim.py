@@ -32,8 +32,15 @@ class HipBertAdam:
         if a.m is None:
             a.m = torch.zeros_like(a.p)
             a.v = torch.zeros_like(a.p)
-        self.descs, self.n_tensors, self.n_blocks = a.build_descs(self.lr, self.bert_lr)
-        self.ws = torch.empty((self.n_blocks + self.n_tensors + 16) * 4, dtype=torch.uint8, device=a.device)
+        # two launch sets: everything but the embedding tables, and the embedding tables.  Under data parallelism the
+        # tables' gradients are the last to be exchanged (the embedding backward is the last kernel); updating the other
+        # 85 M parameters meanwhile hides most of that exchange.
+        is_emb = lambda name: name.startswith("bert_encoder.embeddings.")
+        self.parts = []
+        for sel in (lambda n: not is_emb(n), is_emb):
+            descs, n_t, n_b = a.build_descs(self.lr, self.bert_lr, select=sel)
+            ws = torch.empty((n_b + n_t + 16) * 4, dtype=torch.uint8, device=a.device)
+            self.parts.append((descs, n_t, n_b, ws))
 
     def get_lr_mult(self):
         return warmup_linear(self.step_count, self.t_total, self.warmup)
@@ -41,14 +48,28 @@ class HipBertAdam:
     def zero_grad(self):
         self.arena.g.zero_()
 
-    def step(self):
+    def _launch(self, part):
         a = self.arena
+        descs, n_t, n_b, ws = self.parts[part]
+        if n_t == 0:
+            return
         hb.check(hb.lib().nbest_bertadam_step(hb.ptr(a.p), hb.ptr(a.g), hb.ptr(a.m), hb.ptr(a.v), hb.ptr(a.w16),
-                                              hb.ptr(self.descs), self.n_tensors, self.n_blocks, self.get_lr_mult(),
-                                              self.b1, self.b2, self.e, self.max_grad_norm, hb.ptr(self.ws),
-                                              self.ws.numel(), hb.stream_ptr()), "bertadam_step")
-        a.refresh_transposed()
+                                              hb.ptr(descs), n_t, n_b, self.get_lr_mult(),
+                                              self.b1, self.b2, self.e, self.max_grad_norm, hb.ptr(ws),
+                                              ws.numel(), hb.stream_ptr()), "bertadam_step")
+
+    def step_main(self):
+        """every tensor except the embedding tables (+ the k-contiguous weight copy the next forward / dgrad reads)"""
+        self._launch(0)
+        self.arena.refresh_transposed()
+
+    def step_embeddings(self):
+        self._launch(1)
         self.step_count += 1
+
+    def step(self):
+        self.step_main()
+        self.step_embeddings()
 
     def state_dict(self):
         """per-parameter ``next_m`` / ``next_v`` keyed by parameter name plus the shared step count — the content of

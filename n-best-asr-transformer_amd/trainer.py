@@ -76,22 +76,31 @@ class GradReducer:
         edges = [round(i * L / n_chunks) for i in range(n_chunks + 1)]
         self.chunks = [(edges[i], edges[i + 1]) for i in range(n_chunks) if edges[i + 1] > edges[i]]
         self.pending = []
+        self.pending_emb = []
 
-    def _launch(self, lo, hi):
+    def _launch(self, lo, hi, last=False):
         if dist.is_available() and dist.is_initialized() and hi > lo:
-            self.pending.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            w = dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+            (self.pending_emb if last else self.pending).append(w)
 
     def layers_ready(self, l_lo, l_hi):
-        if not self.pending:
+        if not self.pending and not self.pending_emb:
             self._launch(*self.arena.heads_range)    # head gradients were complete before the encoder backward began
         self._launch(self.arena.layer_range[l_lo][0], self.arena.layer_range[l_hi - 1][1])
         if l_lo == 0:
-            self._launch(*self.arena.emb_range)      # embedding backward is the last kernel of the chunk
+            self._launch(*self.arena.emb_range, last=True)   # embedding backward is the last kernel of the chunk
 
-    def wait(self):
+    def wait_layers(self):
+        """heads + encoder layers exchanged (the embedding tables may still be in flight)"""
         for w in self.pending:
             w.wait()
         self.pending = []
+
+    def wait(self):
+        self.wait_layers()
+        for w in self.pending_emb:
+            w.wait()
+        self.pending_emb = []
 
     def contribute_nothing(self):
         """a rank whose slice of a (short, final) batch is empty still joins every collective of the step, in the same
@@ -112,8 +121,12 @@ def train_step(model, optimizer, batch, add_l2_loss=False, add_segment_ids=True,
                                  trans_seg_ids=batch.get("tseg"), add_l2_loss=add_l2_loss, mse_grad_scale=1.0 / world,
                                  chunks=chunks, on_chunk_done=reducer.layers_ready if reducer is not None else None)
     if reducer is not None:
+        reducer.wait_layers()
+        optimizer.step_main()             # runs while the embedding tables' all-reduce is still in flight
         reducer.wait()
-    optimizer.step()
+        optimizer.step_embeddings()
+    else:
+        optimizer.step()
     return out
 
 

@@ -29,7 +29,11 @@ def _worker(rank, world, port, q):
     assert red.chunks == [(0, 1), (1, 3), (3, 4)]
     for lo, hi in sorted(red.chunks, reverse=True):              # the order the backward produces them
         red.layers_ready(lo, hi)
+    assert len(red.pending) == 4 and len(red.pending_emb) == 1    # heads + 3 layer buckets | embedding tables (last)
+    red.wait_layers()
+    assert red.pending == [] and len(red.pending_emb) == 1
     red.wait()
+    assert red.pending_emb == []
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     want = sum(gathered)
