@@ -308,3 +308,38 @@ def test_full_size_batch_additivity(labels):
     lo, hi = a.layer_range[0][0], a.layer_range[-1][1]
     assert torch.equal(gf[lo:hi], gf2[lo:hi])
     assert torch.equal(gf[a.heads_range[0]:a.heads_range[1]], gf2[a.heads_range[0]:a.heads_range[1]])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_trajectory_tracks_oracle(dtype, labels):
+    """eight optimisation steps (forward, BCE / CE / CLS-MSE losses, backward, BertAdam with warm-up) on changing batches:
+    the per-step loss of the HIP path follows the oracle's (fp32 CPU, autograd) step for step"""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    from nbest_amd.optim import HipBertAdam
+    from nbest_amd.trainer import train_step
+    from oracle import stc
+    from oracle.bertadam import OracleBertAdam
+    from oracle.step import train_step as oracle_step
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = synth.model_state(cfg, labels, seed=17)
+    steps, t_total = 8, 10
+    om = _oracle_for(cfg, sd, labels)
+    oopt = OracleBertAdam(list(om.named_parameters()), lr=2e-4, bert_lr=1e-4, warmup=0.1, t_total=t_total)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0)
+    m.load_reference_state(sd)
+    m.train()
+    opt = HipBertAdam(m, lr=2e-4, bert_lr=1e-4, warmup=0.1, t_total=t_total)
+    b2t = stc.bottom2top_matrix(labels.top2bottom)
+    want, got = [], []
+    for s in range(steps):
+        b = synth.nbest_batch(cfg, labels, 6, 40, n_best=4, seed=300 + s, ragged=True, trans_len=12)
+        rec, _ = oracle_step(om, oopt, {k: torch.from_numpy(v) for k, v in b.items()}, labels.top2bottom, b2t, add_l2_loss=True)
+        want.append(float(rec))
+        out = train_step(m, opt, {k: torch.from_numpy(v).cuda() for k, v in b.items()}, add_l2_loss=True, add_segment_ids=True)
+        got.append(out["loss_parts"].sum().item() / 6)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    for s, (w, g) in enumerate(zip(want, got)):
+        assert abs(w - g) <= tol * abs(w), (s, w, g, want, got)
+    assert want[-1] < want[0]          # and it is actually learning
