@@ -174,6 +174,11 @@ def main():
         dt = tt.item()
     loss = float(out["loss_parts"].sum().item())
     assert np.isfinite(loss), "non-finite loss in the timed region"
+    if distributed:
+        # every rank leaves the process group together, right after the timed region: rank 0's extra measurements
+        # below (dominant-kernel timing) must not keep its peers waiting inside a communicator tear-down
+        dist.barrier()
+        dist.destroy_process_group()
 
     if rank == 0:
         note("timed region: %.3f s, %.1f utt/s" % (dt, a.batch * world * a.steps / dt))
@@ -210,8 +215,6 @@ def main():
             note("cpu baseline (oracle on host cores) ...")
             res["cpu_baseline"] = cpu_baseline(labels)
         print(json.dumps(res), flush=True)
-    if distributed:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
