@@ -1,24 +1,29 @@
 // K2/K4/K6 second generation: bf16 MFMA GEMM with a multi-stage LDS ring kept in flight ACROSS barriers.
 //
 // v1 (gemm_bf16.hip) has one 64-deep K tile in flight per workgroup and drains it (vmcnt(0)) at every
-// barrier: the main loop is load-latency bound (~0.8 PFLOP/s at 4096^3).  Here:
+// barrier.  Here:
 //   * BK = 32 stages in a ring of STAGES LDS buffers; STAGES-1 stages are always in flight.  The wait
-//     that retires stage t is a COUNTED `s_waitcnt vmcnt(n*(STAGES-2))` followed by a raw `s_barrier`
-//     (never __syncthreads(), which would drain the LDS-DMA queue), then stage t+STAGES-1 is issued
-//     into the buffer every wave finished reading one iteration ago.
-//   * tile 256x128 (4 waves, wave tile 128x64 = 8x4 MFMA tiles, 32 MFMA per stage and wave) for the
-//     wide GEMMs: 85 flop per staged byte instead of 64 and 0.375 LDS fragment reads per MFMA instead
-//     of 0.5; 72 KiB LDS -> still two workgroups per CU, so one workgroup's epilogue overlaps the
-//     other's main loop.  Tile 128x128 with a 4-deep ring (64 KiB) where 256x128 would leave CUs idle
-//     (N = 768: 768 tiles on 512 slots) and for the weight gradients (split-K slab traffic grows with
-//     the tile).
+//     that retires stage t is a COUNTED `s_waitcnt vmcnt(n)` followed by a raw `s_barrier` (never
+//     __syncthreads(), which would drain the LDS-DMA queue), then stage t+STAGES-1 is issued into the
+//     buffer every wave finished reading one iteration ago.
+//   * Variants (make_plan picks per shape; what is actually used is listed in DESIGN.md section 4):
+//       256x256, 8 waves, 1 workgroup/CU  "ping-pong": the two waves of every SIMD alternate a LOAD slot
+//                (fragment reads + DMA issue + counted wait) and an MFMA slot (32 MFMAs), one slot out of
+//                phase.  QKV / FFN-up forward, FFN-down dgrad, and - with both operands read transposed -
+//                the QKV / FFN weight gradients (split-K).
+//       256x128 / 128x128, 4 waves, 2 workgroups/CU  plain ring / ring with double-buffered fragments
+//                (kept for the fp32-master fallback layouts and for experiments; v1 wins on N = 768).
+//       gemm2p_kernel  persistent ping-pong (opt-in), see there.
 //   * LDS images (LDS-DMA is lane-linear, so the swizzle lives in the SOURCE address and the read
 //     address): k-contiguous operand [rows][32 k], 64-B rows: chunk ^= (-(row>>2))&3 (conflict-free
 //     for the 16-lane groups of ds_read_b128 even though a group mixes two k-chunks);
 //     k-strided operand [32 k][cols]: chunk ^= 2*(k&3) + 8*((k>>3)&1) for ds_read_b64_tr_b16.
+//   * Transposed reads go through inline asm in the ping-pong loop: the builtin makes the compiler drain
+//     the whole DMA ring (`s_waitcnt vmcnt(0)`) in front of every such read (see ds_read_tr_asm).
 //   * epilogue as v1 (fp32 restage through wave-private LDS into a row-contiguous layout, 16-byte
 //     whole-line I/O, fast erf) but in 32-row chunks, with the residual / pre-activation rows of the
 //     next chunk prefetched while the current one is processed.
+//   * -DNBEST_DIAG=<mask> builds are timing-only ablations / cycle-stamp builds (tools/, profiles/README.md).
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
