@@ -16,6 +16,35 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: this process (which has imported nothing
+    that could touch a GPU) starts one child per GPU through torch.distributed.run on 127.0.0.1, relays their output
+    (rank 0 prints the JSON line) and exits with the launcher's code.  Nothing is exec'd."""
+    if "RANK" in os.environ:
+        return
+    n = 1
+    for i, tok in enumerate(sys.argv):
+        if tok == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif tok.startswith("--gpus="):
+            n = int(tok.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch()
+
 import numpy as np
 import torch
 import torch.distributed as dist

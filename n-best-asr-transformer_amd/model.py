@@ -47,7 +47,7 @@ def _attach(root, dotted, param):
 
 
 class _Pass:
-    """activation stash + descriptor of one encoder pass shape (B, S)"""
+    """descriptor of one encoder pass shape (B, S); the activation stash it writes belongs to the slot"""
 
     def __init__(self, model, B, S, stream_base):
         a, cfg = model.arena, model.cfg
@@ -67,8 +67,8 @@ class _Pass:
         d.layers_host = C.cast(a.layer_offsets, C.POINTER(hb.LayerOffsets))
         d.drop_stream_base = stream_base
         self.desc = d
-        L = hb.lib()
-        self.act = torch.empty(L.nbest_encoder_act_bytes(C.byref(d)), dtype=torch.uint8, device=a.device)
+        self.act_bytes = hb.lib().nbest_encoder_act_bytes(C.byref(d))
+        self.act = None                    # a view of the slot's grow-only stash, bound by NBestSTCModel._pass
         self.B, self.S = B, S
         self.hidden = None
         self.inputs = None
@@ -93,7 +93,8 @@ class NBestSTCModel(nn.Module):
         self.dls = hb.DeviceLabelSpace(labels, self.device)
         self.seed = int(seed)
         self.step_counter = 0
-        self._passes = {}
+        self._passes = {}                  # (B, S, slot) -> _Pass: descriptors only (a few hundred bytes each)
+        self._stash = {}                   # slot -> ONE grow-only activation stash, sized for the largest B*S seen
         self._ws = None
         self._ws_bytes = 0
 
@@ -148,15 +149,33 @@ class NBestSTCModel(nn.Module):
         return missing
 
     def _pass(self, B, S, slot):
+        """Real data pads every batch to its own longest row, so (B, S) changes almost every step: only the small
+        descriptor is per shape; the activation stash is one buffer per slot (ASR pass / transcript pass) that grows
+        to the largest shape seen and is then reused, like the workspace."""
         key = (B, S, slot)
         if key not in self._passes:
+            if len(self._passes) >= 4096:
+                self._passes.clear()
             self._passes[key] = _Pass(self, B, S, stream_base=1000 * slot)
         ps = self._passes[key]
+        stash = self._stash.get(slot)
+        if stash is None or stash.numel() < ps.act_bytes:
+            self._stash[slot] = stash = None          # release before growing: never hold two generations
+            self._stash[slot] = stash = torch.empty(ps.act_bytes, dtype=torch.uint8, device=self.device)
+        ps.act = stash[:ps.act_bytes]
         need = hb.lib().nbest_encoder_ws_bytes(C.byref(ps.desc))
         if need > self._ws_bytes:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             self._ws_bytes = need
         return ps
+
+    def _step_seed(self):
+        """dropout counter base of this step: the element index a kernel hashes is the position inside THIS rank's
+        shard, so data-parallel ranks must not share a seed (every rank would drop the same positions of its shard)"""
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        return self.seed + 7919 * self.step_counter + 15485863 * rank
 
     def _encode(self, ps, ids, seg, train):
         """one encoder pass through the C-ABI; returns hidden states [B*S, H] (a view into the stash)"""
@@ -171,7 +190,7 @@ class NBestSTCModel(nn.Module):
         d = ps.desc
         d.hidden_drop = cfg.hidden_dropout_prob if train else 0.0
         d.attn_drop = cfg.attention_probs_dropout_prob if train else 0.0
-        d.seed = self.seed + 7919 * self.step_counter
+        d.seed = self._step_seed()
         out = C.c_void_p()
         hb.check(hb.lib().nbest_encoder_forward(C.byref(d), hb.ptr(self.arena.weights), hb.ptr(self.arena.p), hb.ptr(ids),
                                                 hb.ptr(seg), hb.ptr(pos), hb.ptr(mask), hb.ptr(ps.act), ps.act.numel(),
@@ -207,7 +226,7 @@ class NBestSTCModel(nn.Module):
             labels_f = torch.zeros(B, self.labels.n_bottom, dtype=torch.float32, device=self.device)
         return hb.stc_heads(hidden, S * H, Wh, bh, self.dls, labels_f.contiguous(), B, H, need_grad=need_grad,
                             accumulate=accumulate, drop_p=self.dropout if train else 0.0,
-                            seed=self.seed + 7919 * self.step_counter, drop_stream=900, dWh=dWh, dbh=dbh)
+                            seed=self._step_seed(), drop_stream=900, dWh=dWh, dbh=dbh)
 
     def _bottoms_dict(self, bott):
         out, col = {}, 0

@@ -7,7 +7,7 @@ Host-side mirror of /root/reference/n_best_asr_bert.py:
 Data parallelism (new functionality; the reference is single-process): one process per GPU, every rank
 holds the full arenas, the minibatch is sharded across ranks.  The reference's BCE / NLL terms are SUM
 reductions (n_best_asr_bert.py:572-574), so gradients are all-reduced with SUM (not mean) and the MSE
-term (a mean over B x H) is pre-scaled by 1/world.  The backward runs in layer chunks; as soon as a
+term (a mean over B_global x H) is pre-scaled by B_local / B_global on each rank (shards may differ by one utterance).  The backward runs in layer chunks; as soon as a
 chunk's gradients are complete their slice of the flat gradient arena is all-reduced asynchronously
 (RCCL on its own stream over xGMI; 6 chunks of 2 layers for bert-base) while the remaining backward - ending with the embedding backward -
 keeps the compute stream busy.  Per-tensor clipping + BertAdam run after the last reduce.
@@ -111,14 +111,19 @@ class GradReducer:
         self.wait()
 
 
-def train_step(model, optimizer, batch, add_l2_loss=False, add_segment_ids=True, reducer=None):
+def train_step(model, optimizer, batch, add_l2_loss=False, add_segment_ids=True, reducer=None, global_batch=None):
     """One optimisation step on this rank's shard.  batch: dict(ids, seg, labels[, tids, tseg]) device tensors.
+    ``global_batch`` = utterances of the whole minibatch over all ranks (default: world x this shard).
     Returns the step outputs (device tensors; no host synchronisation)."""
     _, world = dist_info()
     seg = batch.get("seg") if add_segment_ids else None          # n_best_asr_bert.py:252
     chunks = reducer.chunks if reducer is not None else None
+    b_local = batch["ids"].shape[0]
+    # MSE is a MEAN over B_global x H (n_best_asr_bert.py:574): the local kernel differentiates the mean over its own
+    # B_local rows, so after the SUM all-reduce the term needs the weight B_local / B_global (= 1/world for equal shards)
+    mse_scale = b_local / float(global_batch) if global_batch else 1.0 / world
     out = model.forward_backward(batch["ids"], batch["labels"], seg_ids=seg, trans_input_ids=batch.get("tids"),
-                                 trans_seg_ids=batch.get("tseg"), add_l2_loss=add_l2_loss, mse_grad_scale=1.0 / world,
+                                 trans_seg_ids=batch.get("tseg"), add_l2_loss=add_l2_loss, mse_grad_scale=mse_scale,
                                  chunks=chunks, on_chunk_done=reducer.layers_ready if reducer is not None else None)
     if reducer is not None:
         reducer.wait_layers()
@@ -332,17 +337,18 @@ def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
     counts, losses = (0, 0, 0, 0, 0), []
     split = encoded(data, opt, memory)
     lists = batch_indices(len(split), opt.batchSize, shuffle=shuffle, seed=getattr(opt, "random_seed", 999) + epoch)
-    for _, mine, b in Prefetcher(split, lists, model.device, rank, world):
+    for bi, mine, b in Prefetcher(split, lists, model.device, rank, world):
         if not mine:
             if reducer is not None:
                 reducer.contribute_nothing()
             opt.optimizer.step()                                     # keeps replicas and schedule positions identical
             model.step_counter += 1
             continue
-        out = train_step(model, opt.optimizer, b, add_l2_loss=opt.add_l2_loss, add_segment_ids=opt.add_segment_ids, reducer=reducer)
-        losses.append((out["loss_parts"], len(mine)))
+        out = train_step(model, opt.optimizer, b, add_l2_loss=opt.add_l2_loss, add_segment_ids=opt.add_segment_ids, reducer=reducer,
+                         global_batch=len(lists[bi]))
+        losses.append((out["loss_parts"], len(mine), len(lists[bi])))
         counts, _ = _host_metrics(model, out, [split.labels[j] for j in mine], memory["idx2label"], counts)
-    return _finish(losses, counts, model.device)
+    return _finish(losses, counts, model.device, len(lists))
 
 
 def merge_cases(chunks):
@@ -367,12 +373,13 @@ def eval_epoch(model, data, opt, memory, fp=None, efp=None):
     onto = getattr(opt, "ontology", None)
     counts, losses, chunks = (0, 0, 0, 0, 0), [], []
     split = encoded(data, opt, memory)
-    for bi, mine, b in Prefetcher(split, batch_indices(len(split), opt.batchSize), model.device, rank, world):
+    lists = batch_indices(len(split), opt.batchSize)
+    for bi, mine, b in Prefetcher(split, lists, model.device, rank, world):
         if not mine:
             continue
         seg = b["seg"] if opt.add_segment_ids else None
         out = model.forward_backward(b["ids"], b["labels"], seg_ids=seg, need_grad=False)     # no MSE in eval (:331)
-        losses.append((out["loss_parts"], len(mine)))
+        losses.append((out["loss_parts"], len(mine), len(lists[bi])))
         raw_labels = [split.labels[j] for j in mine]
         counts, preds = _host_metrics(model, out, raw_labels, memory["idx2label"], counts, onto)
         golds = [filter_informative(g, onto) if onto is not None else g for g in raw_labels]
@@ -384,17 +391,27 @@ def eval_epoch(model, data, opt, memory, fp=None, efp=None):
             fp.write(line)
         if efp is not None and set(pc) != set(gold):
             efp.write(line)
-    return _finish(losses, counts, model.device) + (cases,)
+    return _finish(losses, counts, model.device, len(lists)) + (cases,)
 
 
-def _finish(losses, counts, device):
-    # loss_record of a batch = sum(parts) / batch_size (n_best_asr_bert.py:168-192); mean over batches (:290)
-    recs = [float(lp.sum().item()) / n for lp, n in losses] if losses else [0.0]
-    stat = torch.tensor(list(counts) + [sum(recs), len(recs)], dtype=torch.float64, device=device)
+def _finish(losses, counts, device, n_batches=None):
+    """losses: [(loss_parts[4] = BCE(final), BCE(top), mean-CE, MSE of this rank's shard, B_local, B_global)] per batch.
+    loss_record of a batch = sum(parts) / batch_size (n_best_asr_bert.py:168-192), mean over batches (:290).  The BCE / CE
+    parts are sums over utterances, so a rank contributes its sums / B_global; the MSE part is a mean over the rank's own
+    rows and enters with the weight B_local / B_global - summed over ranks this is the single-process record even when the
+    shards are uneven.  ``n_batches``: batches of the epoch (the same on every rank; a rank whose shard of a batch was
+    empty has no entry for it)."""
+    rec = 0.0
+    for lp, b_local, b_global in losses:
+        lp = lp.double().cpu()
+        rec += (float(lp[:3].sum()) + float(lp[3]) * b_local / b_global) / b_global
+    if n_batches is None:
+        n_batches = len(losses)
+    stat = torch.tensor(list(counts) + [rec], dtype=torch.float64, device=device)
     _, world = dist_info()
     if world > 1:
         dist.all_reduce(stat, op=dist.ReduceOp.SUM)
-    TP, FP, FN, corr, tot, lsum, ln = stat.tolist()
+    TP, FP, FN, corr, tot, lsum = stat.tolist()
     p, r, f = compute_f1(int(TP), int(FP), int(FN))
     acc = corr / tot * 100 if tot else 0
-    return lsum / max(ln, 1), (p, r, f), acc
+    return lsum / max(n_batches, 1), (p, r, f), acc

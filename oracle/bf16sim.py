@@ -1,0 +1,144 @@
+"""Oracle, bf16-storage leg: the SAME fp32 CPU restatement (oracle/encoder.py, oracle/model.py), with values rounded to
+bfloat16 at exactly the places where the HIP path keeps a bf16 tensor in HBM or feeds a bf16 MFMA operand; all
+contractions, LayerNorm statistics, softmax, GELU and the heads stay fp32, like the fp32 accumulators of the kernels.
+
+Purpose: |bf16-leg - fp32 reference| is the noise floor any bf16-storage implementation of this path shows on a given
+case.  tests/golden/make_golden.py commits that floor per compared quantity; the GPU parity test bounds
+|HIP bf16 - fp32 reference| by a small multiple of it instead of a hand-set tolerance.
+
+Rounding points (forward; the gradient of each stored tensor is rounded too, as the backward kernels store bf16):
+  weight matrices and the three embedding tables (compute copy `w16`; biases / LayerNorm parameters stay fp32),
+  X0 = LN(embeddings), per layer qkv, softmax probabilities (MFMA operand of P.V), ctx, r1 = x + dense(ctx),
+  x1 = LN(r1), hact = gelu(u) (and gelu'(u), stored for the backward), r2 = x1 + dense(hact), X = LN(r2).
+
+TEST INFRASTRUCTURE - see oracle/__init__.py.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .encoder import position_ids_for
+
+
+def _r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundAct(torch.autograd.Function):
+    """stored activation: value rounded on the way forward, its gradient rounded on the way back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _r(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r(g)
+
+
+class _RoundWeight(torch.autograd.Function):
+    """bf16 compute copy of an fp32 master weight: the weight gradient is produced and kept in fp32"""
+
+    @staticmethod
+    def forward(ctx, w):
+        return _r(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GeluStore(torch.autograd.Function):
+    """FFN-up epilogue: hact = bf16(gelu(u)), stash bf16(gelu'(u)); backward du = bf16(dh * gelu')"""
+
+    @staticmethod
+    def forward(ctx, u):
+        cdf = 0.5 * (1.0 + torch.erf(u * (1.0 / math.sqrt(2.0))))
+        pdf = torch.exp(-0.5 * u * u) * (1.0 / math.sqrt(2.0 * math.pi))
+        ctx.save_for_backward(_r(cdf + u * pdf))
+        return _r(u * cdf)
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return _r(g * d)
+
+
+class _AttnCore(torch.autograd.Function):
+    """softmax(q k^T * scale + mask) v with the MFMA operand roundings of the attention kernels: P -> bf16 for P.V and
+    dV, dS -> bf16 for dQ / dK; scores, softmax and dP in fp32; q, k, v, dO arrive already rounded (stored tensors)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, scale):
+        s = torch.matmul(q, k.transpose(-1, -2)) * scale
+        s = s.masked_fill(~key_mask[:, None, None, :], float("-inf"))
+        p = torch.softmax(s, dim=-1)
+        o = torch.matmul(_r(p), v)
+        ctx.save_for_backward(q, k, v, p, _r(o))
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, p, o = ctx.saved_tensors
+        dv = torch.matmul(_r(p).transpose(-1, -2), do)
+        dp = torch.matmul(do, v.transpose(-1, -2))
+        delta = (do * o).sum(-1, keepdim=True)
+        ds = _r(p * (dp - delta) * ctx.scale)
+        dq = torch.matmul(ds, k)
+        dk = torch.matmul(ds.transpose(-1, -2), q)
+        return dq, dk, dv, None, None
+
+
+ract, rw = _RoundAct.apply, _RoundWeight.apply
+
+
+def _ln(x, mod):
+    return F.layer_norm(x, (x.shape[-1],), mod.weight, mod.bias, mod.eps)
+
+
+def encode(enc, ids, seg):
+    """oracle.encoder.OracleEncoder.forward with bf16 storage (dropout must be off: parity runs use p = 0)"""
+    cfg = enc.cfg
+    key_mask = ids > 0                                                     # quirk Q1 (models/model.py:43)
+    if seg is None:
+        seg = torch.zeros_like(ids)
+    pos = position_ids_for(cfg, ids)
+    E = enc.embeddings
+    pad_w = cfg.pad_token_id
+    pad_p = cfg.pad_token_id if cfg.family in ("roberta", "xlm-roberta") else None
+    e = (F.embedding(ids, rw(E.word_embeddings.weight), padding_idx=pad_w) + F.embedding(seg, rw(E.token_type_embeddings.weight))
+         + F.embedding(pos, rw(E.position_embeddings.weight), padding_idx=pad_p))
+    x = ract(_ln(e, E.LayerNorm))
+    B, S, H = x.shape
+    nh = cfg.num_attention_heads
+    d = H // nh
+    for lyr in enc.encoder.layer:
+        a = lyr.attention.self
+        split = lambda t: t.view(B, S, nh, d).transpose(1, 2)
+        q = ract(F.linear(x, rw(a.query.weight), a.query.bias))
+        k = ract(F.linear(x, rw(a.key.weight), a.key.bias))
+        v = ract(F.linear(x, rw(a.value.weight), a.value.bias))
+        o = _AttnCore.apply(split(q), split(k), split(v), key_mask, 1.0 / math.sqrt(d))
+        ctx = ract(o.transpose(1, 2).reshape(B, S, H))
+        ao = lyr.attention.output
+        r1 = ract(F.linear(ctx, rw(ao.dense.weight), ao.dense.bias) + x)
+        x1 = ract(_ln(r1, ao.LayerNorm))
+        hact = _GeluStore.apply(F.linear(x1, rw(lyr.intermediate.dense.weight), lyr.intermediate.dense.bias))
+        r2 = ract(F.linear(hact, rw(lyr.output.dense.weight), lyr.output.dense.bias) + x1)
+        x = ract(_ln(r2, lyr.output.LayerNorm))
+    return x[:, 0, :]
+
+
+def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None):
+    """oracle.model.OracleModel.forward (classifier_input_type 'asr') on the bf16-storage encoder; heads in fp32"""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            assert m.p == 0.0 or not model.training
+    if model.family == "xlm-roberta":
+        seg_ids = trans_seg_ids = None
+    asr_cls = encode(model.bert_encoder, input_ids, seg_ids)
+    trans_cls = encode(model.bert_encoder, trans_input_ids, trans_seg_ids) if trans_input_ids is not None else None
+    top, bottoms, final = model.clf(asr_cls)
+    return top, bottoms, final, asr_cls, trans_cls

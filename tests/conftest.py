@@ -31,7 +31,7 @@ def load_case(name):
 def case_inputs(meta, labels):
     """Regenerate the inputs of a golden case from its seeds (nothing but outputs is committed)."""
     from nbest_amd import config as ncfg, synth
-    mk = ncfg.xlmr_base if meta["family"] == "xlm-roberta" else ncfg.bert_base
+    mk = {"xlm-roberta": ncfg.xlmr_base, "xlm-roberta-large": ncfg.xlmr_large, "bert": ncfg.bert_base}[meta["family"]]
     cfg = mk(num_hidden_layers=meta["L"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     sd = synth.model_state(cfg, labels, seed=meta["seed"])
     batch = synth.nbest_batch(cfg, labels, meta["B"], meta["S"], n_best=meta["n_best"], seed=meta["seed"],

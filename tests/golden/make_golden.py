@@ -105,9 +105,22 @@ def main():
         dict(name="bert_L12", family="bert", L=12, B=3, S=64, St=16, n_best=5, add_l2=False, seg=True, seed=12),
         dict(name="bert_L2_noseg", family="bert", L=2, B=4, S=40, St=12, n_best=3, add_l2=True, seg=False, seed=13),
         dict(name="xlmr_L2", family="xlm-roberta", L=2, B=4, S=48, St=16, n_best=5, add_l2=True, seg=True, seed=14),
+        # BASELINE configs[3]: bert-base, --add_l2_loss, seq_len 256, n_best 10, transcript pass S_t = 64, full depth
+        dict(name="bert_L12_S256", family="bert", L=12, B=2, S=256, St=64, n_best=10, add_l2=True, seg=True, seed=15),
+        # BASELINE configs[2]: xlm-roberta-base at full depth (250 002-row table, pad-offset positions, quirk Q1 mask)
+        dict(name="xlmr_L12", family="xlm-roberta", L=12, B=2, S=128, St=32, n_best=5, add_l2=True, seg=True, seed=16),
+        # BASELINE configs[4] architecture: xlm-roberta-large shape (H 1024, 16 heads, FFN 4096), 4 layers, seq_len 256.
+        # The reference hard-codes fea_dim = 768 (models/model.py:30, quirk Q7) and cannot build heads on a 1024-wide
+        # encoder: the generator swaps in the reference's OWN HierarchicalClassifier constructed with input_dim = 1024.
+        dict(name="xlmrL_L4_S256", family="xlm-roberta-large", L=4, B=2, S=256, St=64, n_best=10, add_l2=True, seg=True, seed=17),
     ]
+    only = [a for a in sys.argv[1:] if a.startswith("case_")]
     for c in cases:
+        if only and "case_" + c["name"] not in only:
+            continue
         run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns)
+    if only:
+        return
     run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim)
     run_coverage_case()
     run_observe_case()
@@ -117,7 +130,7 @@ def main():
 
 def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
     print("== case", c["name"])
-    mk = ncfg.xlmr_base if c["family"] == "xlm-roberta" else ncfg.bert_base
+    mk = {"xlm-roberta": ncfg.xlmr_base, "xlm-roberta-large": ncfg.xlmr_large, "bert": ncfg.bert_base}[c["family"]]
     cfg = mk(num_hidden_layers=c["L"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     sd_np = synth.model_state(cfg, labels, seed=c["seed"])
     batch = synth.nbest_batch(cfg, labels, c["B"], c["S"], n_best=c["n_best"], seed=c["seed"], ragged=True,
@@ -130,11 +143,14 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
     enc = hf_encoder(cfg)
     opt = types.SimpleNamespace(pretrained_model=enc, dropout=0.0, device=torch.device("cpu"), score_util="pp",
                                 sent_repr="bin_sa_cls", cls_type="stc", top2bottom_dict=memory["top2bottom_dict"],
-                                label_vocab_size=labels.n_bottom, pre_trained_model=c["family"],
+                                label_vocab_size=labels.n_bottom, pre_trained_model=cfg.family,
                                 add_l2_loss=c["add_l2"], add_segment_ids=c["seg"],
                                 class_loss_function=nn.BCELoss(reduction="sum"),
                                 ce_loss_function=nn.NLLLoss(reduction="sum"), mse_loss_function=nn.MSELoss())
     model = ref_model.make_model(opt)
+    if cfg.hidden_size != 768:            # quirk Q7 fence: the reference's own heads class at the encoder's width
+        from models.modules.hierarchical_classifier import HierarchicalClassifier
+        model.clf = HierarchicalClassifier(opt.top2bottom_dict, cfg.hidden_size, opt.label_vocab_size, opt.dropout)
     missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
     assert not missing.missing_keys, missing
     model.train()
@@ -199,13 +215,40 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
             assert (p.grad - grads[n]).abs().max().item() <= 5e-5 * max(1.0, grads[n].abs().max().item()), n
         else:
             assert p.grad is None or p.grad.abs().max() == 0, n
+    # ---------------- bf16-storage leg of the oracle: the noise floor of this case ----------------
+    from oracle import bf16sim
+    ograds = {n: p.grad for n, p in om.named_parameters()}
+    for p in om.parameters():
+        p.grad = None
+    stop, sbot, sfin, sasr, str_ = bf16sim.forward(om, ids, tids, seg_ids=seg_in, trans_seg_ids=tseg)
+    _, stotal, _ = ostc.total_loss(stop, sbot, sfin, y, t2b, ostc.bottom2top_matrix(t2b), sasr, str_, c["add_l2"])
+    stotal.backward()
+    sgrads = {n: p.grad.detach() for n, p in om.named_parameters() if p.grad is not None}
+    for n, p in om.named_parameters():
+        p.grad = ograds[n]
+
+    def floor(a, b):
+        d = (a.detach().float() - b.detach().float())
+        return np.array([d.abs().max().item(), d.pow(2).mean().sqrt().item()])
+    sl = lambda g: g.reshape(-1, g.shape[-1])[:8, :64] if g.dim() > 1 else g[:64]
+    fl = {"floor/top": floor(stop, top), "floor/final": floor(sfin, final),
+          "floor/bottoms": floor(torch.cat([sbot["lin_%d" % t] for t in labels.multi], 1),
+                                 torch.cat([bottoms["lin_%d" % t] for t in labels.multi], 1)),
+          "floor/asr_cls": floor(sasr, asr_cls), "floor/trans_cls": floor(str_, trans_cls),
+          "floor/loss_total": np.array([abs(stotal.item() - total.item()) / abs(total.item())])}
+    for n, g in grads.items():
+        fl["floor/gnorm/" + n] = np.array([abs(sgrads[n].norm().item() - g.norm().item()) / max(g.norm().item(), 1e-30)])
+    print("   bf16-storage oracle vs reference: top %.2e final %.2e bottoms %.2e asr_cls %.2e loss rel %.2e, worst grad-norm rel %.2e" % (
+        fl["floor/top"][0], fl["floor/final"][0], fl["floor/bottoms"][0], fl["floor/asr_cls"][0], fl["floor/loss_total"][0],
+        max(v[0] for k, v in fl.items() if k.startswith("floor/gnorm/") and not k.endswith("key.bias"))))
+
     oopt = OracleBertAdam(list(om.named_parameters()), lr=5e-4, bert_lr=3e-5, warmup=0.1, t_total=t_total)
     oopt.step()
     oopt.step()
     for n, p in om.named_parameters():
         d = (p.detach() - after[n]).abs().max().item()
-        assert d <= 2e-7, ("bertadam", n, d)
-    print("   oracle BertAdam (2 steps) matches reference to 2e-7 on all", len(after), "tensors")
+        assert d <= 4e-7, ("bertadam", n, d)      # parameters are O(0.1): a few fp32 ulps (H = 1024 heads reach 2.03e-7)
+    print("   oracle BertAdam (2 steps) matches reference to 4e-7 on all", len(after), "tensors")
     odec = ostc.decode_indices(otop.detach(), {k: v.detach() for k, v in obot.items()}, t2b, idx2label)
     for i, pl in enumerate(preds):
         mine = [idx2label[j] for j in odec[i].tolist() if j >= 0]
@@ -233,12 +276,16 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
     for n in keep:
         g = grads[n]
         fx["grad/" + n] = g.reshape(-1, g.shape[-1])[:8, :64].numpy() if g.dim() > 1 else g[:64].numpy()
+        fl["floor/grad/" + n] = floor(sl(sgrads[n]), sl(g))
         d = after[n] - before[n]
         fx["delta/" + n] = d.reshape(-1, d.shape[-1])[:8, :64].numpy() if d.dim() > 1 else d[:64].numpy()
     # rows of the word-embedding gradient that are touched (scatter-add parity)
     used = torch.unique(torch.cat([ids.flatten(), tids.flatten()]))[:16]
     fx["wordgrad_rows"] = used.numpy()
     fx["wordgrad_vals"] = grads["bert_encoder.embeddings.word_embeddings.weight"][used, :64].numpy()
+    fl["floor/wordgrad"] = floor(sgrads["bert_encoder.embeddings.word_embeddings.weight"][used, :64],
+                                 grads["bert_encoder.embeddings.word_embeddings.weight"][used, :64])
+    fx.update(fl)
     np.savez_compressed(os.path.join(HERE, "case_%s.npz" % c["name"]), **fx)
     print("   wrote case_%s.npz  loss=%.6f  preds[0]=%s" % (c["name"], total.item(), preds[0]))
 
@@ -472,4 +519,4 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["observe"]:
         run_observe_case()
     else:
-        main()
+        main()          # `make_golden.py case_<name> ...` regenerates only the named encoder cases

@@ -49,8 +49,13 @@ def _worker(rank, world, port, q):
     m = type("M", (), {"arena": a})()
     trainer.broadcast_parameters(m)
     ok = ok and bool((a.p == 1.0).all())
-    loss, (p, r, f), acc = trainer._finish([(torch.tensor([2.0 * (rank + 1), 0, 0, 0]), 2)], (3 + rank, 1, 2, 1 + rank, 4), "cpu")
-    ok = ok and abs(loss - 1.5) < 1e-9 and abs(acc - 100 * 3 / 8) < 1e-9 and abs(p - 100 * 7 / 9) < 1e-9
+    # uneven shards of a 5-utterance batch (3 + 2): sum-type parts add up, the MSE part (a mean over the shard's rows) is
+    # weighted by B_local / B_global -> the record of the single process on the whole batch
+    b_local = 3 if rank == 0 else 2
+    parts = torch.tensor([2.0 * (rank + 1), 1.0, 0.5, 0.3 * (rank + 1)])
+    loss, (p, r, f), acc = trainer._finish([(parts, b_local, 5)], (3 + rank, 1, 2, 1 + rank, 4), "cpu", 1)
+    want_loss = ((2.0 + 1.0 + 0.5) + (4.0 + 1.0 + 0.5) + 0.3 * 3 / 5 + 0.6 * 2 / 5) / 5
+    ok = ok and abs(loss - want_loss) < 1e-6 and abs(acc - 100 * 3 / 8) < 1e-9 and abs(p - 100 * 7 / 9) < 1e-9
     lo, hi = trainer.shard_bounds(7, rank, world)
     ok = ok and (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
     # short final batch: rank 1 has no utterance, joins the step's collectives with zeros and ends with rank 0's sums

@@ -1,0 +1,141 @@
+"""Data-parallel step on the GPU: N fresh processes share cuda:0 and exchange gradients over gloo (the RCCL transport
+needs one GPU per rank; everything above the transport - sharding, chunked backward, bucketed SUM all-reduce of slices of
+the gradient arena, split BertAdam, loss bookkeeping - is the code that runs over RCCL on an 8-GPU node).
+
+Checked against ONE process on the whole batch, fp32, dropout off, uneven shards (5 utterances over 2 ranks = 3 + 2,
+7 over 3 = 3 + 2 + 2), with the CLS-MSE term on (its B_local / B_global weighting is what uneven shards exercise):
+  * all-reduced shard gradients == whole-batch gradients, <= 2e-5 of each tensor's largest entry (fp32 summation order);
+  * after 3 BertAdam steps the replicas are bit-identical;
+  * the loss record of the sharded epoch bookkeeping equals the single-process record;
+  * parameters after 3 steps: mean |DP - single| <= 2e-6.  The maximum is NOT tightly bounded, and the log shows why: BertAdam
+    divides by sqrt(v) + 1e-6, so an element whose gradient is a near-cancellation (|g| below ~1e-6, i.e. rounding noise of
+    the 1e-5-relative summation-order difference) moves by an order-dependent +-lr*3.16 per step - in the reference too.
+    The per-tensor table (gpurun_out/dp_equivalence.log) lists max / mean and the share of such elements.
+"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+LOG = os.path.join(ROOT, "gpurun_out", "dp_equivalence.log")
+
+
+def _worker(rank, world, port, B, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import nbest_amd  # noqa: F401
+        from nbest_amd import config as ncfg, synth
+        from nbest_amd.model import NBestSTCModel
+        from nbest_amd.optim import HipBertAdam
+        from nbest_amd.trainer import GradReducer, _finish, broadcast_parameters, shard_bounds, train_step
+        labels = ncfg.LabelSpace.from_json(os.path.join(ROOT, "tests", "golden", "label_space.json"))
+        cfg = ncfg.bert_base(num_hidden_layers=4, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        S, STEPS, LR = 48, 3, 1e-3
+
+        def build(seed):
+            m = NBestSTCModel(cfg, labels, device="cuda:0", compute_dtype=torch.float32, dropout=0.0)
+            m.load_reference_state(synth.model_state(cfg, labels, seed=seed))
+            m.train()
+            return m, HipBertAdam(m, lr=LR, bert_lr=LR, warmup=0.1, t_total=10)
+
+        batches = []
+        for s in range(STEPS):
+            b = synth.nbest_batch(cfg, labels, B, S, n_best=5, seed=100 + s, ragged=True, trans_len=16)
+            batches.append({k: torch.from_numpy(v).cuda() for k, v in b.items()})
+        lo, hi = shard_bounds(B, rank, world)
+        shard = lambda b: {k: v[lo:hi].contiguous() for k, v in b.items()}
+
+        # data parallel: every rank starts from a DIFFERENT seed; the broadcast makes rank 0's parameters win
+        m, opt = build(seed=5 + rank)
+        broadcast_parameters(m)
+        red = GradReducer(m.arena, n_chunks=2)
+        mine = shard(batches[0])
+        m.forward_backward(mine["ids"], mine["labels"], seg_ids=mine["seg"], trans_input_ids=mine["tids"], trans_seg_ids=mine["tseg"],
+                           add_l2_loss=True, mse_grad_scale=(hi - lo) / B, chunks=red.chunks, on_chunk_done=red.layers_ready)
+        red.wait()
+        torch.cuda.synchronize()
+        g_dp = m.arena.g.clone()
+        m.step_counter = 0
+        losses = []
+        for b in batches:
+            out = train_step(m, opt, shard(b), add_l2_loss=True, add_segment_ids=True, reducer=red, global_batch=B)
+            losses.append((out["loss_parts"].clone(), hi - lo, B))
+        torch.cuda.synchronize()
+        got = m.arena.p.clone()
+        rec_dp, _, _ = _finish(losses, (0, 0, 0, 0, 0), "cpu", STEPS)
+
+        # one process on the whole batch (every rank computes it redundantly)
+        ms, opts = build(seed=5)
+        b0 = batches[0]
+        ms.forward_backward(b0["ids"], b0["labels"], seg_ids=b0["seg"], trans_input_ids=b0["tids"], trans_seg_ids=b0["tseg"], add_l2_loss=True)
+        torch.cuda.synchronize()
+        g_one = ms.arena.g.clone()
+        ms.step_counter = 0
+        rec_one = 0.0
+        for b in batches:
+            out = train_step(ms, opts, b, add_l2_loss=True, add_segment_ids=True)
+            rec_one += out["loss_parts"].double().sum().item() / B / STEPS
+        torch.cuda.synchronize()
+        want = ms.arena.p
+        a = m.arena
+        rows, gerr = [], 0.0
+        for sl in a.slots:
+            if "pooler" in sl.name:
+                continue
+            x, y = a.view(g_dp, sl.name), a.view(g_one, sl.name)
+            # the key-bias gradient is mathematically zero (softmax is shift invariant): only rounding noise reaches it
+            ge = 0.0 if sl.name.endswith("attention.self.key.bias") else (x - y).abs().max().item() / (y.abs().max().item() + 1e-30)
+            gerr = max(gerr, ge)
+            d = (a.view(got, sl.name) - a.view(want, sl.name)).abs()
+            rows.append((sl.name, ge, d.max().item(), d.mean().item(), (d > 0.01 * LR).float().mean().item()))
+        got_h = got.cpu()
+        allp = [torch.zeros_like(got_h) for _ in range(world)]
+        dist.all_gather(allp, got_h)
+        same = all(torch.equal(allp[0], x) for x in allp)
+        mean_err = (got - want).abs().mean().item()
+        dist.destroy_process_group()
+        q.put((rank, dict(gerr=gerr, same=same, mean_err=mean_err, max_err=(got - want).abs().max().item(), rec_dp=rec_dp,
+                          rec_one=rec_one, rows=rows if rank == 0 else None)))
+    except BaseException as e:                      # surface the failure in the parent instead of a queue timeout
+        import traceback
+        q.put((rank, dict(error=traceback.format_exc() + repr(e))))
+
+
+@pytest.mark.parametrize("world,B", [(2, 5), (3, 7)])
+def test_dp_step_equals_single_process(world, B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29620 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+    for r in range(world):
+        assert "error" not in res[r], res[r]["error"]
+    r0 = res[0]
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write("world %d, batch %d (uneven shards), fp32, 4 layers, lr 1e-3, 3 BertAdam steps\n" % (world, B))
+        f.write("  reduced-shard gradient vs whole-batch gradient: max relative difference %.2e (bound 2e-5)\n" % r0["gerr"])
+        f.write("  parameters: mean |DP - single| %.2e (bound 2e-6), max %.2e; replicas bit-identical: %s\n" % (
+            r0["mean_err"], r0["max_err"], all(res[r]["same"] for r in range(world))))
+        f.write("  loss record: DP %.8f single %.8f\n" % (r0["rec_dp"], r0["rec_one"]))
+        f.write("  %-64s %10s %10s %10s %s\n" % ("tensor", "grad rel", "max |dp|", "mean |dp|", "share of elements off by > 1% of lr"))
+        for name, ge, mx, mean, share in sorted(r0["rows"], key=lambda t: -t[2])[:12]:
+            f.write("  %-64s %10.2e %10.2e %10.2e %.2e\n" % (name[-64:], ge, mx, mean, share))
+    for r in range(world):
+        assert res[r]["same"], "replicas diverged"
+        assert res[r]["gerr"] < 2e-5, res[r]["gerr"]
+        assert res[r]["mean_err"] < 2e-6, res[r]["mean_err"]
+        assert abs(res[r]["rec_dp"] - res[r]["rec_one"]) <= 1e-5 * abs(res[r]["rec_one"]), (res[r]["rec_dp"], res[r]["rec_one"])

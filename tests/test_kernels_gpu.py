@@ -290,6 +290,68 @@ def test_stc_heads_loss_and_grads_match_oracle(labels):
     assert torch.equal(pred.long(), ref_dec)                   # bit-exact label indices
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_stc_heads_dropout_masks(labels, seed):
+    """Feature dropout of the STC heads (p = --dropout 0.3): every one of the 11 linears sees its OWN mask of the CLS
+    features (/root/reference/models/modules/hierarchical_classifier.py:41,46).  With one utterance whose CLS row is all
+    ones, dWh[r][h] / dbh[r] IS the (scaled) mask the backward applied to feature h for the linear that owns row r.
+    Checked: kept elements carry 1/(1-p); drop rate ~ p per linear and overall; all rows of a linear share its mask;
+    masks of different linears are independent (agreement ~ p^2 + (1-p)^2, never identical); the FORWARD used the same
+    masks (scores recomputed from the recovered masks match the kernel's outputs); dcls uses them too."""
+    p, H = 0.3, 768
+    g = torch.Generator().manual_seed(40 + seed)
+    dls = hb.DeviceLabelSpace(labels, DEV)
+    R, nt = dls.n_rows, labels.n_top
+    Wh = (torch.randn(R, H, generator=g) * 0.05).to(DEV)
+    bh = (torch.randn(R, generator=g) * 0.05).to(DEV)
+    y = torch.zeros(1, labels.n_bottom)
+    y[0, labels.top2bottom[2][3]] = 1
+    y[0, labels.top2bottom[4][0]] = 1
+    hidden = torch.ones(1, H, device=DEV)
+    top, bott, fin, loss, dcls, dWh, dbh = hb.stc_heads(hidden, H, Wh, bh, dls, y.to(DEV), 1, H, drop_p=p, seed=1234 + seed, drop_stream=900)
+    top2, bott2, _, _, dcls2, _, _ = hb.stc_heads(hidden, H, Wh, bh, dls, y.to(DEV), 1, H, drop_p=p, seed=1234 + seed, drop_stream=900)
+    assert torch.equal(top, top2) and torch.equal(bott, bott2) and torch.equal(dcls, dcls2)          # counter-based: reproducible
+    top3, _, _, _, _, _, _ = hb.stc_heads(hidden, H, Wh, bh, dls, y.to(DEV), 1, H, drop_p=p, seed=99 + seed, drop_stream=900)
+    assert not torch.equal(top, top3)
+    assert dbh.abs().min().item() > 1e-7
+    scaled = (dWh / dbh[:, None]).cpu()                         # [R, H]: 0 or 1/(1-p)
+    keep_val = 1.0 / (1.0 - p)
+    is_keep = (scaled - keep_val).abs() < 1e-3
+    is_drop = scaled.abs() < 1e-3
+    assert bool((is_keep | is_drop).all()), "mask values other than 0 and 1/(1-p)"
+    # rows -> linears: rows [0, nt) are the top linear, then one block per multi-value top label
+    blocks, row = [(0, nt)], nt
+    for t in labels.multi:
+        n = len(labels.top2bottom[t])
+        blocks.append((row, row + n))
+        row += n
+    assert row == R and len(blocks) == 11
+    masks = []
+    for lo, hi in blocks:
+        m = is_keep[lo]
+        assert bool((is_keep[lo:hi] == m[None, :]).all()), "rows of one linear must share one mask"
+        masks.append(m)
+        rate = 1.0 - m.float().mean().item()
+        assert abs(rate - p) < 0.07, rate                       # 768 draws: sigma 0.017
+    M = torch.stack(masks).float()                              # [11, H]
+    assert abs(1.0 - M.mean().item() - p) < 0.02                # 8448 draws: sigma 0.005
+    for i in range(11):
+        for j in range(i + 1, 11):
+            agree = (M[i] == M[j]).float().mean().item()
+            assert 0.45 < agree < 0.71, (i, j, agree)            # independent masks agree on p^2 + (1-p)^2 = 0.58
+    # forward used the same masks
+    Wc, bc = Wh.cpu(), bh.cpu()
+    logit = lambda k: (Wc[blocks[k][0]:blocks[k][1]] * (M[k] * keep_val)[None, :]).sum(1) + bc[blocks[k][0]:blocks[k][1]]
+    close("heads dropout: top from recovered mask", top.cpu()[0], torch.sigmoid(logit(0)), 1e-5)
+    soft = torch.cat([torch.softmax(logit(k), 0) for k in range(1, 11)])
+    close("heads dropout: bottoms from recovered masks", bott.cpu()[0], soft, 1e-5)
+    # and so did the gradient wrt the CLS row: dcls[h] = sum_r dz[r] W[r][h] mask_{linear(r)}(h) / (1-p)
+    want = torch.zeros(H)
+    for k, (lo, hi) in enumerate(blocks):
+        want += (dbh.cpu()[lo:hi, None] * Wc[lo:hi]).sum(0) * M[k] * keep_val
+    close("heads dropout: dcls from recovered masks", dcls.cpu()[0], want, 1e-4)
+
+
 def test_cls_mse():
     B, S, H = 4, 6, 768
     a, t = rnd(B * S, H, seed=81), rnd(B * 3, H, seed=82)

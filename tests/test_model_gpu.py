@@ -52,57 +52,97 @@ def _cmp(name, got, ref, atol=None, rtol=None):
     assert err <= bound, "%s: |err| %.3e > %.3e (scale %.3e)" % (name, err, bound, scale)
 
 
-CASES = ["bert_L2", "bert_L2_noseg", "xlmr_L2", "bert_L12"]
+CASES = ["bert_L2", "bert_L2_noseg", "xlmr_L2", "bert_L12",
+         "bert_L12_S256",        # BASELINE configs[3]: --add_l2_loss, seq_len 256, n_best 10, S_t 64, 12 layers
+         "xlmr_L12",             # BASELINE configs[2]: xlm-roberta-base, 12 layers, seq_len 128
+         "xlmrL_L4_S256"]        # BASELINE configs[4] architecture: xlm-roberta-large shape, 4 layers, seq_len 256
+FLOOR_FACTOR = 1.5
+
+
+def _cmp_floor(name, got, ref, floor_max):
+    """bf16 bar: |HIP - fp32 reference| <= 1.5 x |bf16-storage oracle - fp32 reference| (the committed noise floor of this
+    quantity on this case, oracle/bf16sim.py) plus half a bf16 ulp of the tensor's scale"""
+    got = torch.as_tensor(got).float().cpu()
+    ref = torch.as_tensor(ref).float()
+    err = (got - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-12)
+    bound = FLOOR_FACTOR * floor_max + scale * 2.0 ** -9
+    _log("%-64s abs_err=%.3e floor=%.3e ratio=%.2f bound=%.3e %s" % (name, err, floor_max, err / max(floor_max, 1e-30), bound,
+                                                                      "OK" if err <= bound else "FAIL"))
+    assert err <= bound, "%s: |err| %.3e > %.3e (bf16 floor %.3e, scale %.3e)" % (name, err, bound, floor_max, scale)
 
 
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_step_matches_reference_outputs(name, dtype, labels):
+    """fp32 path: north_star bars (scores 1e-4, bit-exact decode).  bf16 path: every compared quantity within 1.5 x the
+    committed bf16-storage noise floor of the same case (see _cmp_floor); where that floor allows, this is <= 1e-2 on
+    the scores (2-layer cases: floors 4e-3..5e-3; 12 layers: the floor itself is 0.7e-2..1.1e-2, logged)."""
     meta, z = load_case(name)
     m, b, out = _run(meta, labels, dtype)
     f32 = dtype == torch.float32
     tag = "%s/%s " % (name, "f32" if f32 else "bf16")
-    # fp32: 1e-4 (north_star).  bf16: 1e-2 on scores for the 2-layer cases; the 12-layer stack stores bf16
-    # activations 8x per layer, and its measured drift against the fp32 reference is 1.1e-2 -> bound 2e-2.
-    a = 1e-4 if f32 else (1e-2 if meta["L"] <= 2 else 2e-2)
-    _cmp(tag + "top", out["top"], z["top"], atol=a)
-    _cmp(tag + "final", out["final"], z["final"], atol=a)
-    _cmp(tag + "bottoms", out["bott"], z["bottoms"], atol=a)
-    hid = dict(atol=2e-4) if f32 else dict(rtol=1.5e-2 if meta["L"] <= 2 else 2e-2)   # CLS hidden rows are O(4)
-    _cmp(tag + "asr_cls", out["asr_cls"], z["asr_cls"], **hid)
+    fl = lambda k: float(z["floor/" + k][0])
+    for key, val in (("top", out["top"]), ("final", out["final"]), ("bottoms", out["bott"])):
+        if f32:
+            _cmp(tag + key, val, z[key], atol=1e-4)
+        else:
+            _cmp_floor(tag + key, val, z[key], fl(key))
+    if f32:
+        _cmp(tag + "asr_cls", out["asr_cls"], z["asr_cls"], atol=2e-4 if meta["L"] <= 2 else 4e-4)        # CLS rows are O(4)
+    else:
+        _cmp_floor(tag + "asr_cls", out["asr_cls"], z["asr_cls"], fl("asr_cls"))
     if meta["add_l2"]:
-        _cmp(tag + "trans_cls", out["trans_cls"], z["trans_cls"], **hid)
+        if f32:
+            _cmp(tag + "trans_cls", out["trans_cls"], z["trans_cls"], atol=2e-4 if meta["L"] <= 2 else 4e-4)
+        else:
+            _cmp_floor(tag + "trans_cls", out["trans_cls"], z["trans_cls"], fl("trans_cls"))
     lp = out["loss_parts"].cpu()
     total = float(lp.sum())
     ref_total = float(z["loss_total"])
-    _log(tag + "loss total %.6f vs reference %.6f" % (total, ref_total))
-    assert abs(total - ref_total) <= (1e-4 if f32 else 1e-2) * abs(ref_total)
-    # hidden-state slices of the first encoder pass (ASR ids)
-    B, S, H = meta["B"], meta["S"], m.cfg.hidden_size
+    lbound = 1e-4 if f32 else FLOOR_FACTOR * fl("loss_total") + 2.0 ** -9
+    _log(tag + "loss total %.6f vs reference %.6f (rel %.2e, bound %.2e)" % (total, ref_total, abs(total - ref_total) / abs(ref_total), lbound))
+    assert abs(total - ref_total) <= lbound * abs(ref_total)
     if f32:
         dec = m.decode(out["top"], out["bott"]).cpu().numpy()
         assert np.array_equal(dec, z["decode"]), "decoded label indices differ from the reference"
     named = dict(m.named_parameters())
+    # gradients.  fp32: 2e-3 of each tensor's norm / scale.  bf16: no tensor may be further from the fp32 reference than
+    # 1.5 x the WORST tensor of the bf16-storage oracle on this case (per-tensor floors can be small by chance)
+    # (separately for the encoder tensors and for the small STC heads, whose softmax gradients are far more sensitive)
+    gn_floors = {grp: max(float(z[k][0]) for k in z.files if k.startswith("floor/gnorm/" + grp) and not k.endswith("attention.self.key.bias"))
+                 for grp in ("bert_encoder.", "clf.")}
+    gs_floor = max(float(z[k][0]) / max(float(np.abs(z["grad/" + k[11:]]).max()), 1e-30) for k in z.files
+                   if k.startswith("floor/grad/") and not k.endswith("attention.self.key.bias"))
+    gs_floor = max(gs_floor, float(z["floor/wordgrad"][0]) / max(float(np.abs(z["wordgrad_vals"]).max()), 1e-30))
+    worst_gn = {"bert_encoder.": 0.0, "clf.": 0.0}
     for key in z.files:
         if key.startswith("gnorm/"):
             g = named[key[6:]].grad
             ref = float(z[key])
             got = g.norm().item()
-            _log("%-64s got=%.5e ref=%.5e" % (tag + key[-48:], got, ref))
             if key.endswith("attention.self.key.bias"):
-                # mathematically ZERO (softmax is invariant to a key bias): both sides are rounding noise,
-                # so bound it against the query-bias gradient of the same layer instead of against itself
+                # mathematically ZERO (softmax is invariant to a key bias): both sides are rounding noise.  fp32: bound
+                # it against the query-bias gradient of the same layer; bf16: against the noise the bf16-storage oracle
+                # leaves there (its norm = ref * (1 + committed relative floor), the fp32 reference being ~1e-7)
                 qn = named[key[6:].replace(".key.", ".query.")].grad.norm().item()
-                assert got <= (1e-5 if f32 else 2e-2) * qn, key
+                sim = ref * (1.0 + float(z["floor/" + key][0]))
+                _log("%-64s got=%.3e bf16-storage oracle=%.3e query-bias norm=%.3e" % (tag + key[-44:], got, sim, qn))
+                assert got <= (1e-5 * qn if f32 else FLOOR_FACTOR * sim), key
                 continue
-            assert abs(got - ref) <= (2e-3 if f32 else 4e-2) * max(ref, 1e-6) + (1e-7 if f32 else 1e-4), key
+            rel = abs(got - ref) / max(ref, 1e-6)
+            grp = "clf." if key[6:].startswith("clf.") else "bert_encoder."
+            worst_gn[grp] = max(worst_gn[grp], rel)
+            assert abs(got - ref) <= (2e-3 if f32 else FLOOR_FACTOR * gn_floors[grp]) * max(ref, 1e-6) + (1e-7 if f32 else 1e-4), (key, got, ref)
         elif key.startswith("grad/") and not key.endswith("attention.self.key.bias"):
             g = named[key[5:]].grad
             got = g.reshape(-1, g.shape[-1])[:8, :64] if g.dim() > 1 else g[:64]
-            _cmp(tag + key[-52:], got, z[key], rtol=2e-3 if f32 else 6e-2)
+            _cmp(tag + key[-52:], got, z[key], rtol=2e-3 if f32 else FLOOR_FACTOR * gs_floor + 2.0 ** -8)
+    for grp in worst_gn:
+        _log(tag + "worst gradient-norm rel err of %-13s %.3e (worst bf16-storage floor %.3e)" % (grp + "*", worst_gn[grp], gn_floors[grp]))
     rows = torch.from_numpy(z["wordgrad_rows"]).cuda()
     wg = named["bert_encoder.embeddings.word_embeddings.weight"].grad
-    _cmp(tag + "word-embedding grad rows", wg[rows, :64], z["wordgrad_vals"], rtol=2e-3 if f32 else 6e-2)
+    _cmp(tag + "word-embedding grad rows", wg[rows, :64], z["wordgrad_vals"], rtol=2e-3 if f32 else FLOOR_FACTOR * gs_floor + 2.0 ** -8)
 
 
 @pytest.mark.parametrize("name", ["bert_L2", "xlmr_L2"])
@@ -175,35 +215,59 @@ def test_xlmr_large_shape_matches_oracle(dtype, labels):
 def _check_vs_oracle(cfg, B, S, St, dtype, labels):
     from nbest_amd import synth
     from nbest_amd.model import NBestSTCModel
-    from oracle import stc
+    from oracle import bf16sim, stc
     sd = synth.model_state(cfg, labels, seed=31)
     n_best = 2 if S < 16 else 5
     batch = synth.nbest_batch(cfg, labels, B, S, n_best=n_best, seed=S, ragged=True, trans_len=St)
     om = _oracle_for(cfg, sd, labels)
     t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    b2t = stc.bottom2top_matrix(labels.top2bottom)
     top, bottoms, final, asr, tr = om(t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"])
-    rec, total, parts = stc.total_loss(top, bottoms, final, t["labels"], labels.top2bottom, stc.bottom2top_matrix(labels.top2bottom),
-                                       asr, tr, True)
+    rec, total, parts = stc.total_loss(top, bottoms, final, t["labels"], labels.top2bottom, b2t, asr, tr, True)
     total.backward()
+    ref_g = {n: p.grad.detach().clone() for n, p in om.named_parameters() if p.grad is not None}
+    f32 = dtype == torch.float32
+    fl_top = fl_fin = fl_loss = 0.0
+    fl_gn = {"bert_encoder.": 0.0, "clf.": 0.0}
+    if not f32:
+        # noise floor of THIS case: the same oracle with bf16 storage (oracle/bf16sim.py) against its fp32 self
+        for p in om.parameters():
+            p.grad = None
+        stop, sbot, sfin, sasr, str_ = bf16sim.forward(om, t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"])
+        _, stotal, _ = stc.total_loss(stop, sbot, sfin, t["labels"], labels.top2bottom, b2t, sasr, str_, True)
+        stotal.backward()
+        fl_top, fl_fin = (stop - top).abs().max().item(), (sfin - final).abs().max().item()
+        fl_loss = abs(stotal.item() - total.item()) / abs(total.item())
+        for n, p in om.named_parameters():
+            if n in ref_g and not n.endswith("attention.self.key.bias"):
+                grp = "clf." if n.startswith("clf.") else "bert_encoder."
+                fl_gn[grp] = max(fl_gn[grp], abs(p.grad.norm().item() - ref_g[n].norm().item()) / max(ref_g[n].norm().item(), 1e-6))
     m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0)
     m.load_reference_state(sd)
     m.train()
     b = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
     out = m.forward_backward(b["ids"], b["labels"], seg_ids=b["seg"], trans_input_ids=b["tids"], trans_seg_ids=b["tseg"], add_l2_loss=True)
-    f32 = dtype == torch.float32
-    tag = "edge B=%d S=%d %s " % (B, S, "f32" if f32 else "bf16")
-    _cmp(tag + "top", out["top"], top.detach(), atol=1e-4 if f32 else 1e-2)
-    _cmp(tag + "final", out["final"], final.detach(), atol=1e-4 if f32 else 1e-2)
-    assert abs(out["loss_parts"].sum().item() - total.item()) <= (1e-4 if f32 else 1e-2) * abs(total.item())
+    tag = "edge %s B=%d S=%d %s " % (cfg.family, B, S, "f32" if f32 else "bf16")
+    if f32:
+        _cmp(tag + "top", out["top"], top.detach(), atol=1e-4)
+        _cmp(tag + "final", out["final"], final.detach(), atol=1e-4)
+    else:
+        _cmp_floor(tag + "top", out["top"], top.detach(), fl_top)
+        _cmp_floor(tag + "final", out["final"], final.detach(), fl_fin)
+    assert abs(out["loss_parts"].sum().item() - total.item()) <= (1e-4 if f32 else FLOOR_FACTOR * fl_loss + 2.0 ** -9) * abs(total.item())
     named = dict(m.named_parameters())
-    for n, p in om.named_parameters():
-        if p.grad is None or n.endswith("attention.self.key.bias"):
+    worst = {"bert_encoder.": 0.0, "clf.": 0.0}
+    for n, g_ref in ref_g.items():
+        if n.endswith("attention.self.key.bias"):
             continue
-        ref = p.grad.norm().item()
+        ref = g_ref.norm().item()
         got = named[n].grad.norm().item()
-        # bf16 with one or two utterances: a single sample's softmax-head gradient moves ~10 % under bf16 hidden states
-        rel = 2e-3 if f32 else (5e-2 if B > 2 else 2e-1)
-        assert abs(got - ref) <= rel * max(ref, 1e-6) + (1e-6 if f32 else 1e-3), (n, got, ref)
+        grp = "clf." if n.startswith("clf.") else "bert_encoder."
+        worst[grp] = max(worst[grp], abs(got - ref) / max(ref, 1e-6))
+        rel = 2e-3 if f32 else FLOOR_FACTOR * fl_gn[grp]
+        assert abs(got - ref) <= rel * max(ref, 1e-6) + (1e-6 if f32 else 1e-3), (n, got, ref, rel)
+    _log(tag + "worst grad-norm rel err: encoder %.2e (floor %.2e)  heads %.2e (floor %.2e)" % (
+        worst["bert_encoder."], fl_gn["bert_encoder."], worst["clf."], fl_gn["clf."]))
     if f32:
         dec = stc.decode_indices(top.detach(), {k: v.detach() for k, v in bottoms.items()}, labels.top2bottom, labels.idx2label)
         assert torch.equal(m.decode(out["top"], out["bott"]).cpu().long(), dec)
@@ -219,6 +283,41 @@ def test_too_long_sequence_fails_loudly(labels):
     ids = torch.randint(5, 2000, (1, 300), device="cuda")
     with pytest.raises(RuntimeError, match="S=300"):
         m.forward_backward(ids, torch.zeros(1, labels.n_bottom, device="cuda"))
+
+
+def test_activation_stash_is_bounded_over_varying_shapes(labels):
+    """real data pads every batch to its own longest row: (B, S) changes almost every step.  The activation stash is one
+    grow-only buffer per pass slot, so device memory plateaus at the largest shape instead of growing per distinct shape"""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.bfloat16, dropout=0.3)
+    m.load_reference_state(synth.model_state(cfg, labels, seed=2))
+    m.train()
+    rng = np.random.default_rng(0)
+
+    def step(B, S, St):
+        b = synth.nbest_batch(cfg, labels, B, S, n_best=5, seed=S, ragged=True, trans_len=St)
+        t = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+        m.forward_backward(t["ids"], t["labels"], seg_ids=t["seg"], trans_input_ids=t["tids"], trans_seg_ids=t["tseg"], add_l2_loss=True)
+        m.eval()
+        m(None, t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"])
+        m.train()
+        del t
+        torch.cuda.synchronize()
+
+    step(16, 200, 40)                                    # the largest shape first: everything after must fit in it
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    seen = set()
+    for _ in range(24):
+        B, S, St = int(rng.integers(1, 17)), int(rng.integers(20, 201)), int(rng.integers(8, 41))
+        seen.add((B, S))
+        step(B, S, St)
+        assert torch.cuda.memory_allocated() <= base + (1 << 20), (B, S, torch.cuda.memory_allocated(), base)
+    assert len(seen) >= 20
+    assert len(m._stash) == 2 and len(m._passes) >= 20   # two stashes (ASR / transcript pass), one small descriptor per shape
 
 
 def test_training_step_is_hip_graph_capturable(labels):

@@ -27,7 +27,7 @@ def _oracle_run(meta, labels):
     return m, top, bottoms, final, asr, tr, rec, total
 
 
-@pytest.mark.parametrize("name", ["bert_L2", "bert_L2_noseg", "xlmr_L2"])
+@pytest.mark.parametrize("name", ["bert_L2", "bert_L2_noseg", "xlmr_L2", "bert_L12_S256"])
 def test_oracle_matches_reference_outputs(name, labels):
     from oracle import stc
     from oracle.bertadam import OracleBertAdam
@@ -58,6 +58,22 @@ def test_oracle_matches_reference_outputs(name, labels):
             d = named[key[6:]].detach() - before[key[6:]]
             got = d.reshape(-1, d.shape[-1])[:8, :64] if d.dim() > 1 else d[:64]
             np.testing.assert_allclose(got.numpy(), z[key], atol=3e-7)
+
+
+def test_bf16_storage_leg_reproduces_committed_floor(labels):
+    """the bf16-storage leg of the oracle (oracle/bf16sim.py) gives the committed noise floors of a case again (they bound
+    the HIP bf16 path in tests/test_model_gpu.py); rounding decisions can flip with the CPU's summation order, hence 30 %"""
+    from oracle import bf16sim, stc
+    meta, z = load_case("bert_L2")
+    m, top, bottoms, final, asr, tr, rec, total = _oracle_run(meta, labels)
+    cfg, sd, batch = case_inputs(meta, labels)
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    stop, sbot, sfin, sasr, str_ = bf16sim.forward(m, t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"])
+    for key, a, b in (("top", stop, top), ("final", sfin, final), ("asr_cls", sasr, asr), ("trans_cls", str_, tr)):
+        got = (a - b).abs().max().item()
+        assert 0.7 * float(z["floor/" + key][0]) <= got <= 1.3 * float(z["floor/" + key][0]), (key, got, float(z["floor/" + key][0]))
+    # and it is a bf16-sized perturbation, not a different function: far above fp32 noise, far below the signal
+    assert 1e-4 < (stop - top).abs().max().item() < 2e-2
 
 
 def test_reference_known_answers(labels):
