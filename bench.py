@@ -56,9 +56,33 @@ from nbest_amd.optim import HipBertAdam
 from nbest_amd.trainer import GradReducer, broadcast_parameters, init_distributed, train_step
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X (MI355X_MICROARCH.md)
-# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-# KiB -> bytes), measured on configs[1]; see profiles/README.md.  None until measured.
-TRAFFIC_BYTES_PER_LAUNCH = 332.8e6   # (2 x 134 460 KiB FETCH_SIZE + 56 081 KiB WRITE_SIZE) x 1024, avg of the layer's 4 launches
+
+
+def wgrad_traffic_from_profiles():
+    """HBM bytes per weight-gradient launch (the GEMM plus its split-K reduce) from the newest tracked PMC table
+    profiles/rNN_pmc.csv (tools/profile_step.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very
+    command, gfx950 corrections applied by tools/pmc_table.py).  Returns (bytes or None, provenance string)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))
+    if not files:
+        return None, "no profiles/r*_pmc.csv"
+    total, launches = 0.0, 0.0
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            k = row["kernel"]
+            is_gemm = ("gemm2_kernel" in k or "gemm_bf16_kernel" in k) and k.rstrip(">").endswith(", 6")   # EPI = F32_SPLITK
+            if not (is_gemm or "splitk_reduce" in k):
+                continue
+            n, tb = float(row["launches_per_step"]), float(row["traffic_bytes_per_launch"])
+            if tb != tb:
+                continue
+            total += n * tb
+            if is_gemm:
+                launches += n
+    if not launches:
+        return None, "no weight-gradient rows in %s" % os.path.basename(files[-1])
+    return total / launches, "profiles/%s (rocprofv3 --pmc, FETCH_SIZE x2 x1024 + WRITE_SIZE x1024, GEMM + split-K reduce)" % os.path.basename(files[-1])
 
 
 def flops_per_utt(cfg, S, St=0):
@@ -98,40 +122,39 @@ def cpu_baseline(labels, seconds_budget=25.0):
                 sample="%d steps of bert-base fp32 B=8 S=128 n_best=5 (fwd+loss+bwd+BertAdam), oracle on CPU" % n)
 
 
-def time_dominant_kernel(M, H, F, iters=10):
-    """The kernel with the largest share of the step (rocprof: profiles/): the weight-gradient GEMM
-    (dW = dY^T . X over the M = B*S token rows, split-K, fp32 out; the 256x256 ping-pong kernel
-    gemm2_kernel<...,true,true,F32_SPLITK> for the QKV / FFN gradients, gemm_bf16_kernel<true,true,F32_SPLITK> for the
-    768x768 attention-output gradient).
-    It is launched four times per layer (QKV, attention-out, FFN-up, FFN-down); this times that set on the
-    launch stream with HIP events and returns (avg ms per launch, avg algorithmic flops per launch,
-    avg algorithmic bytes per launch = both bf16 operands read once + the fp32 gradient written once)."""
-    dev = "cuda"
-    r = lambda *s: (torch.randn(*s, device=dev) * 0.5).bfloat16()
-    x, big = r(M, H), r(M, F)
-    shapes = [(3 * H, H, r(M, 3 * H), x), (H, H, r(M, H), x), (F, H, big, x), (H, F, r(M, H), big)]
-    outs = [torch.empty(n, k, dtype=torch.float32, device=dev) for n, k, _, _ in shapes]
-
-    launchers = [hb.gemm_prepared(dy, a, n, k, M, o, True, True, hb.EPI_F32_SPLITK, defer_reduce=True)   # the GEMM kernel alone
-                 for (n, k, dy, a), o in zip(shapes, outs)]
-
-    # each shape is launched `iters` times in a row: like in the training step, where dY was written by the kernel just
-    # before, the operands are then (partly) resident in the 256 MB Infinity Cache.  Cycling through the four shapes
-    # (650 MB of operands) instead measures cold HBM reads and disagrees with the in-step rocprof average by 25 %.
-    for f in launchers:
-        f()
-        f()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for f in launchers:
-        for _ in range(iters):
-            f()
-    e1.record()
+def time_wgrad_in_step(model, step, B, S, n_steps=3):
+    """The kernel with the largest share of the step (profiles/): the weight-gradient GEMM dW = dY^T . X over the
+    M = B*S token rows (split-K, fp32 out), launched four times per layer (FFN-down, FFN-up, attention-out, QKV).
+    Timed IN the training step, on the launch stream, with HIP events the library records around each of the 4 L
+    launches (nbest_encoder_desc::wgrad_events; a launch = the GEMM kernel + its split-K reduce): `n_steps` further
+    steps right after the timed region, same cache / clock / power state as the step itself.
+    Returns (avg ms per launch, avg algorithmic flops per launch, avg algorithmic bytes per launch = both bf16 operands
+    read once + the fp32 gradient written once)."""
+    import ctypes as C
+    cfg = model.cfg
+    H, F, L, M = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, B * S
+    n_ev = 8 * L
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)]
+    for e in evs:
+        e.record()                                  # torch creates the hipEvent_t lazily, at the first record
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / (iters * len(shapes))
-    flops = sum(2.0 * M * n * k for n, k, _, _ in shapes) / len(shapes)
-    byts = sum(2.0 * M * (n + k) + 4.0 * n * k for n, k, _, _ in shapes) / len(shapes)
-    return ms, flops, byts
+    arr = (C.c_void_p * n_ev)(*[e.cuda_event for e in evs])
+    desc = model._pass(B, S, 0).desc
+    desc.wgrad_events, desc.wgrad_events_n = C.cast(arr, C.POINTER(C.c_void_p)), n_ev
+    tot, n = 0.0, 0
+    try:
+        for _ in range(n_steps):
+            step()
+            torch.cuda.synchronize()
+            for i in range(4 * L):
+                tot += evs[2 * i].elapsed_time(evs[2 * i + 1])
+                n += 1
+    finally:
+        desc.wgrad_events, desc.wgrad_events_n = None, 0
+    shapes = [(H, F), (F, H), (H, H), (3 * H, H)]
+    flops = sum(2.0 * M * a * b for a, b in shapes) / 4
+    byts = sum(2.0 * M * (a + b) + 4.0 * a * b for a, b in shapes) / 4
+    return tot / n, flops, byts
 
 
 def note(msg):
@@ -151,6 +174,7 @@ def main():
     ap.add_argument("--add_l2_loss", action="store_true")
     ap.add_argument("--no_dropout", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true", help="skip the in-step event timing (profiler passes)")
     a = ap.parse_args()
 
     rank, world, local = init_distributed()
@@ -228,17 +252,20 @@ def main():
             "step_mfma_frac": round(utt * fpu / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "last_loss_per_utt": round(loss / a.batch, 4),
         }
-        if a.dtype == "bf16":
-            ms, fl, by = time_dominant_kernel(a.batch * a.seq_len, cfg.hidden_size, cfg.intermediate_size)
+        if a.dtype == "bf16" and not a.no_roofline:
+            ms, fl, by = time_wgrad_in_step(model, step, a.batch, a.seq_len)
             ach = fl / (ms * 1e-3) / 1e12
+            traffic, src = wgrad_traffic_from_profiles() if (a.model == "bert" and a.batch == 256 and a.seq_len == 128) else (None, "not measured for this shape")
+            H_, F_ = cfg.hidden_size, cfg.intermediate_size
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
                                "kernel": "weight-gradient GEMM dW = dY^T.X (both operands token-major, transposed LDS reads, split-K, fp32 "
                                          "out; gemm2_kernel<256,256,...,true,true,F32_SPLITK> for QKV/FFN, gemm_bf16_kernel<true,true,"
-                                         "F32_SPLITK> for the attention output), K = %d token rows; avg over the 4 launches of a layer: "
-                                         "%dx%d, %dx%d, %dx%d, %dx%d" % (a.batch * a.seq_len, 3 * cfg.hidden_size, cfg.hidden_size,
-                                                                        cfg.hidden_size, cfg.hidden_size, cfg.intermediate_size,
-                                                                        cfg.hidden_size, cfg.hidden_size, cfg.intermediate_size),
+                                         "F32_SPLITK> for the attention output, each followed by its split-K reduce), K = %d token rows; "
+                                         "avg over the 4 launches of a layer: %dx%d, %dx%d, %dx%d, %dx%d" % (
+                                             a.batch * a.seq_len, H_, F_, F_, H_, H_, H_, 3 * H_, H_),
+                               "timing": "HIP events recorded by the library around each of the %d launches per step, on the launch "
+                                         "stream, inside 3 training steps run right after the timed region" % (4 * cfg.num_hidden_layers),
                                "avg_launch_ms": round(ms, 4), "flops_per_launch": fl, "algorithmic_bytes_per_launch": by}
         if world == 1 and not a.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")

@@ -253,7 +253,12 @@ typedef struct nbest_encoder_desc {
   const nbest_layer_offsets* layers_host; /* [L], HOST memory */
   uint64_t seed;
   uint32_t drop_stream_base; /* distinct per encoder pass within a step */
-  int32_t pad;
+  int32_t wgrad_events_n;    /* entries of wgrad_events (0 = no timing) */
+  /* optional in-step timing of the weight-gradient GEMMs (bench.py's roofline object): caller-created hipEvent_t
+   * handles; nbest_encoder_backward records wgrad_events[2*i] before and [2*i+1] after the i-th weight-gradient
+   * launch it enqueues (4 per layer, highest layer first: FFN-down, FFN-up, attention-out, QKV), on the caller's
+   * stream, while i < wgrad_events_n / 2.  The library never creates, waits on or destroys events.            */
+  void** wgrad_events;
 } nbest_encoder_desc;
 size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
 size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);

@@ -56,11 +56,15 @@ def parse_arguments(argv=None):
     g = ap.add_argument_group("encoder")
     g.add_argument("--bert_model_name", default="bert-base-uncased")
     g.add_argument("--fix_bert_model", action="store_true")
-    g.add_argument("--pre_trained_model", help="bert | roberta | xlm-roberta")
+    g.add_argument("--pre_trained_model", help="bert | xlm-roberta (| xlm-roberta-large).  'roberta' is refused: the reference hands "
+                   "segment ids to RoBERTa's one-row token-type table and dies with an IndexError (models/model.py:56)")
     g.add_argument("--tod_pre_trained_model", help="ToD-BERT style checkpoint: keeps [SYS]/[USR] markers")
     g = ap.add_argument_group("training / testing")
     g.add_argument("--testing", action="store_true")
-    g.add_argument("--deviceId", type=int, default=-1, help="-1 is rejected (no CPU path); >= 0: GPU of this process")
+    g.add_argument("--deviceId", type=int, default=-1,
+                   help="as the reference (n_best_asr_bert.py:116-126): 0 = pick a GPU automatically (here: the first visible one; "
+                        "the reference asks gpustat / NVML for the least loaded), k > 0 = GPU k-1, -1 = CPU (refused: the path is "
+                        "HIP-only).  Under torchrun every rank uses its LOCAL_RANK GPU instead")
     g.add_argument("--random_seed", type=int, default=999)
     g.add_argument("--l2", type=float, default=0)
     g.add_argument("--dropout", type=float, default=0.0)
@@ -69,7 +73,9 @@ def parse_arguments(argv=None):
     g.add_argument("--max_norm", type=float, default=5.0)
     g.add_argument("--max_epoch", type=int, default=50)
     g.add_argument("--experiment", default="exp")
-    g.add_argument("--optim_choice", default="bertadam", choices=["adam", "adamw", "bertadam"])
+    g.add_argument("--optim_choice", default="bertadam", choices=["adam", "adamw", "bertadam"],
+                   help="only bertadam (the shipped script's choice) is built as a fused HIP optimizer; adam / adamw "
+                        "(n_best_asr_bert.py:552-569: torch Adam, HF AdamW + linear schedule, global-norm clip) are refused")
     g.add_argument("--lr", type=float, default=5e-4)
     g.add_argument("--bert_lr", type=float, default=1e-5)
     g.add_argument("--warmup_proportion", type=float, default=0.1)
@@ -97,6 +103,16 @@ def parse_arguments(argv=None):
         ap.error("only --optim_choice bertadam is built (the shipped script's choice)")
     if opt.deviceId < 0:
         ap.error("--deviceId -1 (CPU) is not available: the path is HIP-only")
+    if opt.pre_trained_model == "roberta":
+        ap.error("--pre_trained_model roberta: the reference passes segment ids (1 after the first separator) to RoBERTa's "
+                 "one-row token-type table in both encoder passes (models/model.py:45,56; n_best_asr_bert.py:255) and fails "
+                 "with an IndexError; use bert or xlm-roberta")
+    if opt.pre_trained_model and opt.pre_trained_model not in ncfg.NAMED:
+        ap.error("--pre_trained_model %s: known shapes are %s" % (opt.pre_trained_model, ", ".join(sorted(ncfg.NAMED))))
+    opt.gpu_index = 0 if opt.deviceId == 0 else opt.deviceId - 1            # n_best_asr_bert.py:116-126 (0: auto -> first GPU)
+    # gradient accumulation exactly as the reference derives it (n_best_asr_bert.py:522): 4 micro-batches of batchSize / 4
+    # per optimizer step when --n_layers 12 is passed (the shipped script never passes it -> 1)
+    opt.n_accum_steps = 4 if opt.n_layers == 12 else 1
     opt.ontology = None if opt.ontology_path is None else json.load(open(opt.ontology_path))       # n_best_asr_bert.py:138-140
     return opt
 
@@ -155,7 +171,7 @@ class _Log:
 def main(argv=None):
     opt = parse_arguments(argv)
     rank, world, local = trainer.init_distributed()
-    dev = torch.device("cuda", local if world > 1 else opt.deviceId)
+    dev = torch.device("cuda", local if world > 1 else opt.gpu_index)
     torch.cuda.set_device(dev)
     random.seed(opt.random_seed)
     np.random.seed(opt.random_seed)

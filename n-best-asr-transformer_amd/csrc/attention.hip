@@ -1,7 +1,7 @@
 // K3 / K3b: scaled-dot-product attention with a per-sample key-padding mask, forward and backward.
 //
 // bf16 path (production): one workgroup (4 waves) per (sample, head); the whole K and V of a head
-// live in LDS (S <= 256, d = 64: 2 x 32 KiB), filled by LDS-DMA (buffer_load ... lds) straight from the
+// live in LDS (S <= 256, d = 64: 2 x 32 KiB; 256 < S <= 512: see the long-sequence kernels), filled by LDS-DMA (buffer_load ... lds) straight from the
 // fused qkv activation [M][3H] - the sequence's own buffer descriptor zero-fills rows past S.
 //   forward : wave = 32 query rows.  scores are computed SWAPPED, S^T = K . Q^T with
 //             v_mfma_f32_32x32x16_bf16, so a lane owns ONE query row (half of its keys; the other
@@ -613,6 +613,316 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
   }
 }
 
+
+// =================================================================================================
+// long sequences, 256 < S <= 512 (BERT's position table ends at 512; the reference never truncates,
+// /root/reference/utils/bert_xlnet_inputs.py:87-94).  Same tiles, operand tricks and LDS images as above, but
+// nothing is sized by a compile-time S: the key-block count is a runtime argument.
+//   forward : K and V of the head stay in LDS (2 x 64 KiB at S = 512, one workgroup per CU); a wave walks the key blocks
+//             TWICE per 32-query block - pass 1 keeps only the running row max / sum-exp (online softmax), pass 2
+//             recomputes the scores and feeds the normalised bf16 probabilities to the P.V MFMA - so no score tile has
+//             to survive in registers across key blocks.
+//   backward: 8 waves; the keys are processed in halves of 256 (wave = 32 keys of the current half, K half in LDS);
+//             Q and dO are STREAMED through a double-buffered [32][64] LDS block per query block (LDS-DMA of block
+//             qb+1 overlaps the math of block qb); dQ of query block qb is accumulated across the halves in the
+//             registers of wave qb mod 8 (two blocks per wave at S = 512).
+// =================================================================================================
+// rows [row_off, row_off + nrows) of a sequence -> LDS rows 0.. (swizzle by the LDS row); nrows * 8 chunks, nt threads
+__device__ __forceinline__ void stage_rows_off(__amdgpu_buffer_rsrc_t rs, char* tile, int nrows, int row_off, int col_off, int ld,
+                                               int t, int nt) {
+  const int chunks = nrows * 8;
+  for (int p = t; p < chunks; p += nt) {
+    const int row = p >> 3, slot = p & 7;
+    const int c = slot ^ gsw(row);
+    const uint32_t voff = (uint32_t)(((row_off + row) * ld + col_off + c * 8) * 2);
+    // LDS-DMA writes lane-linear from a wave-uniform base: chunk p of this wave's 64 lands at base + lane * 16
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (p & ~63) * 16), 16, voff, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_long_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                                 bf16* __restrict__ ctx, float* __restrict__ lse, int S, int nkb,
+                                                                 int heads, int H, float scale, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int Sp = nkb * 32;
+  char* Kt = lds;
+  char* Vt = lds + Sp * 128;
+  float* madd = (float*)(lds + 2 * Sp * 128);
+  char* Ost = lds + 2 * Sp * 128 + Sp * 4;  // 4 x 4 KiB, one [32][64] image per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int ld = 3 * H;
+  const bf16* base = qkv + (int64_t)b * S * ld;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(S * ld * 2), 0x00020000);
+  stage_rows(rs, Kt, Sp, H + h * 64, ld, tid);
+  stage_rows(rs, Vt, Sp, 2 * H + h * 64, ld, tid);
+  for (int k = tid; k < Sp; k += 256) madd[k] = (k < S && mask[b * S + k]) ? 0.f : -INFINITY;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int qb = wave; qb < nkb; qb += 4) {
+    const int q0 = 32 * qb, qrow = q0 + (lane & 31);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const i32x4 raw = (qrow < S) ? *(const i32x4*)(base + (int64_t)qrow * ld + h * 64 + 16 * ks + 8 * hh) : i32x4{0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(bf16x8, raw);
+    }
+    // ---- pass 1: running max m and sum-exp l over this lane's half of the keys ----
+    float m = -INFINITY, l = 0.f;
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; ++kb) {
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, 32 * kb, ks, lane), qf[ks], a, 0, 0, 0);
+      float bm = -INFINITY;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 ma = *(const f32x4*)(madd + 32 * kb + 8 * r4 + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = a[4 * r4 + e] * scale + ma[e];
+          a[4 * r4 + e] = v;
+          bm = fmaxf(bm, v);
+        }
+      }
+      const float mn = fmaxf(m, bm);
+      if (mn > -INFINITY) {
+        float add = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add += __expf(a[r] - mn);
+        l = ((m > -INFINITY) ? l * __expf(m - mn) : 0.f) + add;
+      }
+      m = mn;
+    }
+    const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
+    const float mx = fmaxf(m, mo);
+    const float mxs = (mx == -INFINITY) ? 0.f : mx;
+    const float sum = ((m > -INFINITY) ? l * __expf(m - mxs) : 0.f) + ((mo > -INFINITY) ? lo * __expf(mo - mxs) : 0.f);
+    const float inv = 1.0f / sum;
+    if (hh == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = mxs + __logf(sum);
+    // ---- pass 2: probabilities (recomputed) -> dropout -> P . V ----
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    const uint32_t rowbase = (uint32_t)((bh * S + qrow) * S);
+    const bool pair_hash = drop.thr16 && (S & 1) == 0;
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; ++kb) {
+      f32x16 a;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, 32 * kb, ks, lane), qf[ks], a, 0, 0, 0);
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 ma = *(const f32x4*)(madd + 32 * kb + 8 * r4 + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[4 * r4 + e] = __expf(a[4 * r4 + e] * scale + ma[e] - mxs) * inv;
+      }
+      if (pair_hash) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const uint32_t idx = rowbase + (uint32_t)(32 * kb + crow(r, hh));
+          const uint32_t hsh = nb_hash32((idx >> 1) * 0x9E3779B9U + drop.key);
+          a[r] = ((hsh & 0xFFFFu) >= drop.thr16) ? a[r] * drop.scale : 0.f;
+          a[r + 1] = ((hsh >> 16) >= drop.thr16) ? a[r + 1] * drop.scale : 0.f;
+        }
+      } else if (drop.thr16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = nb_keep(drop, rowbase + (uint32_t)(32 * kb + crow(r, hh))) ? a[r] * drop.scale : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pa = acc_to_frag(a, s);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 0, lane), o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 32, lane), o1, 0, 0, 0);
+      }
+    }
+    store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0);
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                                 const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+                                                                 const float* __restrict__ lse, bf16* __restrict__ dqkv,
+                                                                 float* __restrict__ colpart, int S, int nkb, int heads, int H,
+                                                                 float scale, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NW = 8, NT = 512, KH = 256, RS = 512;   // keys per half; dS slab row stride (256 keys x 2 B)
+  const int Sp = nkb * 32;
+  char* Qs = lds;                                       // [2][32][128 B]
+  char* dOs = Qs + 2 * 4096;                            // [2][32][128 B]
+  char* Kt = dOs + 2 * 4096;                            // [KH][128 B]; after a half: 8 x 4 KiB output images
+  char* dSb = Kt + KH * 128;                            // [2][32][RS]
+  float* lse_s = (float*)(dSb + 2 * 32 * RS);
+  float* del_s = lse_s + Sp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int ld = 3 * H;
+  const bf16* base = qkv + (int64_t)b * S * ld;
+  const bf16* dobase = dctx + (int64_t)b * S * H;
+  const bf16* obase = ctx + (int64_t)b * S * H;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(S * ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, (uint32_t)(S * H * 2), 0x00020000);
+  for (int k = tid; k < Sp; k += NT) lse_s[k] = (k < S) ? lse[(int64_t)bh * S + k] : INFINITY;
+  for (int r = tid >> 1; r < Sp; r += NT / 2) {   // delta[q] = sum_d dO[q][d] * O[q][d]; two threads per row
+    const int half = tid & 1;
+    float sdel = 0.f;
+    if (r < S) {
+      const bf16* dp = dobase + (int64_t)r * H + h * 64 + 32 * half;
+      const bf16* op = obase + (int64_t)r * H + h * 64 + 32 * half;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a[8], o[8];
+        Vec8<bf16>::load(dp + 8 * c, a);
+        Vec8<bf16>::load(op + 8 * c, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sdel = fmaf(a[j], o[j], sdel);
+      }
+    }
+    sdel += __shfl_xor(sdel, 1, 64);
+    if (half == 0) del_s[r] = sdel;
+  }
+  f32x16 dqa0, dqa1, dqb0, dqb1;                  // dQ of query blocks `wave` and `wave + 8`
+  float ck0 = 0.f, ck1 = 0.f, cv0 = 0.f, cv1 = 0.f;   // column sums of dK / dV over the halves (bias gradient)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dqa0[r] = dqa1[r] = dqb0[r] = dqb1[r] = 0.f;
+  const int nkh = (nkb + 7) / 8;
+
+#pragma unroll 1
+  for (int kh = 0; kh < nkh; ++kh) {
+    const int key0 = KH * kh;
+    const int nkb_h = (nkb - 8 * kh < 8) ? nkb - 8 * kh : 8;
+    __syncthreads();                               // the previous half is done with Kt (output images), Qs / dOs and the slabs
+    stage_rows_off(rs, Kt, KH, key0, H + h * 64, ld, tid, NT);
+    if (wave < 4) stage_rows_off(rs, Qs, 32, 0, h * 64, ld, tid, 256);
+    else stage_rows_off(rsd, dOs, 32, 0, h * 64, H, tid - 256, 256);
+    const int keyl = 32 * wave + (lane & 31), key = key0 + keyl;
+    const bool active = wave < nkb_h;
+    const bool kvalid = active && key < S;
+    const float mk = (kvalid && mask[b * S + key]) ? 0.f : -INFINITY;
+    // K row fragments are re-read from LDS and V row fragments from L2 in every query block: holding them (32 registers)
+    // next to two dQ tile pairs would spill
+    const bf16* vrow = base + (int64_t)(kvalid ? key : 0) * ld + 2 * H + h * 64 + 8 * hh;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk0[r] = dk1[r] = dv0[r] = dv1[r] = 0.f;
+
+#pragma unroll 1
+    for (int qb = 0; qb < nkb; ++qb) {
+      const int cur = qb & 1;
+      const char* Qc = Qs + cur * 4096;
+      const char* dOc = dOs + cur * 4096;
+      char* slab = dSb + cur * 32 * RS;
+      if (qb + 1 < nkb) {                          // block qb+1 -> the buffers everyone finished reading before the last barrier
+        if (wave < 4) stage_rows_off(rs, Qs + (cur ^ 1) * 4096, 32, 32 * (qb + 1), h * 64, ld, tid, 256);
+        else stage_rows_off(rsd, dOs + (cur ^ 1) * 4096, 32, 32 * (qb + 1), h * 64, H, tid - 256, 256);
+      }
+      if (active) {
+        f32x16 sa, da;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[r] = da[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const i32x4 raw = kvalid ? *(const i32x4*)(vrow + 16 * ks) : i32x4{0, 0, 0, 0};
+          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qc, 0, ks, lane), row_frag(Kt, 32 * wave, ks, lane), sa, 0, 0, 0);
+          da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOc, 0, ks, lane), __builtin_bit_cast(bf16x8, raw), da, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 l4 = *(const f32x4*)(lse_s + 32 * qb + 8 * r4 + 4 * hh);
+          const f32x4 d4 = *(const f32x4*)(del_s + 32 * qb + 8 * r4 + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * r4 + e;
+            const int ql = 8 * r4 + 4 * hh + e;
+            const int q = 32 * qb + ql;
+            const float pv = __expf(sa[r] * scale + mk - l4[e]);
+            float pt = pv, dp = da[r];
+            if (drop.thr16) {
+              const bool keep = nb_keep(drop, (uint32_t)((bh * S + q) * S + key));
+              pt = keep ? pv * drop.scale : 0.f;
+              dp = keep ? dp * drop.scale : 0.f;
+            }
+            const float ds = pv * (dp - d4[e]) * scale;
+            sa[r] = pt;
+            da[r] = ds;
+            *(bf16*)(slab + ql * RS + ((((keyl >> 3) ^ (ql & 15))) << 4) + (keyl & 7) * 2) = (bf16)ds;
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pa = acc_to_frag(sa, s2), dsa = acc_to_frag(da, s2);
+          dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(dOc, 16 * s2, 0, lane), dv0, 0, 0, 0);
+          dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(dOc, 16 * s2, 32, lane), dv1, 0, 0, 0);
+          dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, tr_frag<true>(Qc, 16 * s2, 0, lane), dk0, 0, 0, 0);
+          dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, tr_frag<true>(Qc, 16 * s2, 32, lane), dk1, 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of block qb+1 has landed
+      __syncthreads();                                    // slab of block qb complete; block qb+1 visible to everyone
+      if (wave == (qb & 7)) {                             // dQ[qb] += dS[qb, this half] . K[this half]
+        // accumulated straight into the owning register pair (a temporary pair would push the kernel into scratch)
+#define NB_DQ_ACC(D0, D1)                                                                                      \
+  _Pragma("unroll 1") for (int ks = 0; ks < 2 * nkb_h; ++ks) {                                                 \
+    const int row = lane & 31;                                                                                 \
+    const int c = 2 * ks + hh;                                                                                 \
+    const bf16x8 dsf = *(const bf16x8*)(slab + row * RS + ((c ^ (row & 15)) << 4));                            \
+    D0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 0, lane), D0, 0, 0, 0);      \
+    D1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 32, lane), D1, 0, 0, 0);     \
+  }
+        if (qb < 8) { NB_DQ_ACC(dqa0, dqa1) } else { NB_DQ_ACC(dqb0, dqb1) }
+#undef NB_DQ_ACC
+      }
+    }
+    __syncthreads();   // the last dQ update has read Kt and its slab: Kt becomes 8 output images
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ck0 += dk0[r]; ck1 += dk1[r]; cv0 += dv0[r]; cv1 += dv1[r]; }
+      const int r0 = key0 + 32 * wave;
+      bf16* g = dqkv + ((int64_t)b * S + r0) * ld + h * 64;
+      store_tile(Kt + wave * 4096, 0, dk0, dk1, lane, g + H, ld, S - r0);
+      store_tile(Kt + wave * 4096, 0, dv0, dv1, lane, g + 2 * H, ld, S - r0);
+    }
+  }
+  __syncthreads();
+  if (colpart) {
+    float* cs = (float*)dSb;   // [NW][3][64]
+    float cq0 = 0.f, cq1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { cq0 += dqa0[r] + dqb0[r]; cq1 += dqa1[r] + dqb1[r]; }
+    float v6[6] = {cq0, cq1, ck0, ck1, cv0, cv1};
+#pragma unroll
+    for (int t6 = 0; t6 < 6; ++t6) {
+      float x = v6[t6];
+      x += __shfl_xor(x, 32, 64);
+      if (lane < 32) cs[(wave * 3 + (t6 >> 1)) * 64 + (t6 & 1) * 32 + lane] = x;
+    }
+    __syncthreads();
+    if (tid < 192) {
+      const int which = tid >> 6, dcol = tid & 63;
+      float x = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) x += cs[(w2 * 3 + which) * 64 + dcol];
+      colpart[(int64_t)b * 3 * H + which * H + h * 64 + dcol] = x;
+    }
+  }
+  // dQ: wave w holds query blocks w and w + 8
+  if (wave < nkb) {
+    const int r0 = 32 * wave;
+    store_tile(Kt + wave * 4096, 0, dqa0, dqa1, lane, dqkv + ((int64_t)b * S + r0) * ld + h * 64, ld, S - r0);
+  }
+  if (wave + 8 < nkb) {
+    const int r0 = 32 * (wave + 8);
+    store_tile(Kt + wave * 4096, 0, dqb0, dqb1, lane, dqkv + ((int64_t)b * S + r0) * ld + h * 64, ld, S - r0);
+  }
+}
+
 static size_t bwd2_lds_bytes(int nkb) {
   const int Sp = nkb * 32, rs = (Sp <= 128) ? 256 : 512;
   return (size_t)Sp * 128 * 3 + (size_t)2 * 32 * rs + (size_t)Sp * 8;
@@ -665,9 +975,16 @@ extern "C" int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, voi
     NB_CHECK(S <= 512, NBEST_ERR_SHAPE, "attention_fwd(f32): S=%d > 512", S);
     attn_fwd_f32_kernel<<<dim3(B * heads, (S + 127) / 128), 128, 0, st>>>((const float*)qkv, key_mask, (float*)ctx, lse, S, heads, H, scale, dc);
   } else {
-    NB_CHECK(S <= 256, NBEST_ERR_SHAPE, "attention_fwd(bf16): S=%d > 256", S);
+    NB_CHECK(S <= 512, NBEST_ERR_SHAPE, "attention_fwd(bf16): S=%d > 512", S);
     NB_CHECK((int64_t)S * 3 * H * 2 < ((int64_t)1 << 31), NBEST_ERR_SHAPE, "attention_fwd: sequence too large");
     const int nkb = (S + 31) / 32;
+    if (nkb > 8) {
+      const size_t sm = fwd_lds_bytes(nkb);
+      (void)hipFuncSetAttribute((const void*)attn_fwd_long_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+      attn_fwd_long_bf16_kernel<<<B * heads, 256, sm, st>>>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, S, nkb, heads, H, scale, dc);
+      NB_LAUNCH_CHECK();
+      return NBEST_OK;
+    }
 #define F(N) case N: launch_fwd<N>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, S, heads, H, scale, dc, st); break;
     switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
 #undef F
@@ -705,9 +1022,18 @@ extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, con
     if (dbias) return nbest_colsum(dqkv, dbias, (int64_t)B * S, 3 * H, 3 * H, NBEST_F32, accumulate, ws, ws_bytes, stream);
     return NBEST_OK;
   }
-  NB_CHECK(S <= 256, NBEST_ERR_SHAPE, "attention_bwd(bf16): S=%d > 256", S);
+  NB_CHECK(S <= 512, NBEST_ERR_SHAPE, "attention_bwd(bf16): S=%d > 512", S);
   const int nkb = (S + 31) / 32;
   float* colpart = dbias ? (float*)ws : nullptr;
+  if (nkb > 8) {
+    const size_t sm = (size_t)2 * 4096 * 2 + 256 * 128 + 2 * 32 * 512 + (size_t)nkb * 32 * 8;
+    (void)hipFuncSetAttribute((const void*)attn_bwd_long_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    attn_bwd_long_bf16_kernel<<<B * heads, 512, sm, st>>>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse,
+                                                         (bf16*)dqkv, colpart, S, nkb, heads, H, scale, dc);
+    NB_LAUNCH_CHECK();
+    if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
+    return NBEST_OK;
+  }
   // NBEST_ATTN_BWD=1 selects the first structure (everything in LDS, S <= 128) for A/B measurements
   static const int old_structure = [] { const char* e = getenv("NBEST_ATTN_BWD"); return (e && e[0] == '1') ? 1 : 0; }();
   if (old_structure && nkb <= 4) {

@@ -100,6 +100,11 @@ static int check_desc(const nbest_encoder_desc* d) {
   NB_CHECK(d->dtype == NBEST_F32 || d->dtype == NBEST_BF16, NBEST_ERR_DTYPE, "encoder: bad dtype %d", d->dtype);
   NB_CHECK(d->B > 0 && d->S > 0 && d->L > 0 && d->heads > 0, NBEST_ERR_SHAPE, "encoder: bad shape");
   NB_CHECK(d->H == d->heads * 64, NBEST_ERR_SHAPE, "encoder: hidden %d != heads %d x 64", d->H, d->heads);
+  // the reference never truncates (utils/bert_xlnet_inputs.py:87-94) and would index past the position table; fail up
+  // front instead, before anything is enqueued (RoBERTa-family positions start at pad_id + 1)
+  NB_CHECK(d->S + (d->pos_pad_id >= 0 ? (int)d->pos_pad_id + 1 : 0) <= d->max_pos, NBEST_ERR_SHAPE,
+           "encoder: S=%d does not fit the position table (%d rows)", d->S, d->max_pos);
+  NB_CHECK(d->S <= 512, NBEST_ERR_SHAPE, "encoder: S=%d > 512", d->S);
   if (d->dtype == NBEST_BF16)
     NB_CHECK(d->H % 128 == 0 && d->F % 128 == 0, NBEST_ERR_SHAPE, "encoder(bf16): H and F must be multiples of 128");
   return NBEST_OK;
@@ -214,6 +219,12 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   void* dB1 = W + w.dB1; void* dctx = W + w.dctx; void* dBig = W + w.dBig; void* dqkv = W + w.dqkv;
   void* red = W + w.red; void* slab = W + w.slab;
   const uint32_t sb = d->drop_stream_base;
+  // optional in-step timing of the weight-gradient GEMMs (see nbest_encoder_desc::wgrad_events)
+  int ev_i = 4 * (d->L - layer_end);
+  auto stamp = [&](int which) {
+    if (d->wgrad_events && 2 * ev_i + which < d->wgrad_events_n) (void)hipEventRecord((hipEvent_t)d->wgrad_events[2 * ev_i + which], st);
+    ev_i += which;
+  };
 
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const nbest_layer_offsets& o = d->layers_host[l];
@@ -229,26 +240,34 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     // (the FFN-up bias gradient = column sums of dU is fused into this epilogue)
     RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red, w.red_bytes, accumulate,
              0.f, 0, 0, st, G(o.b1)));
+    stamp(0);
     RUN(gemm(dt, dRd, hact, G(o.w2), H, F, M, H, F, F, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
+    stamp(1);
     // FFN-up: dgrad + residual gradient ; wgrad
     RUN(gemm(dt, dBig, PT.W(o.w1), dB1, M, H, F, F, wt ? F : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    stamp(0);
     RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
+    stamp(1);
     // LN1 backward
     RUN(nbest_layernorm_bwd(dB1, r1, st1, P.P(o.ln1_g), dR, hdrop ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt, accumulate,
                             d->hidden_drop, d->seed, s0 + 1, red, w.red_bytes, stream));
     // attention output projection: dgrad ; wgrad
     RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    stamp(0);
     RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
+    stamp(1);
     // attention backward -> dqkv ; QKV bias gradient
     RUN(nbest_attention_bwd(qkv, key_mask, ctx, dctx, lse, dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64, dt,
                             d->attn_drop, d->seed, s0 + 0, stream));
     // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
     RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    stamp(0);
     RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
              w.slab_bytes, accumulate, 0.f, 0, 0, st));
+    stamp(1);
   }
   if (!with_embeddings) return NBEST_OK;
   if (!accumulate) {

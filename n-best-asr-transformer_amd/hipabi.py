@@ -61,7 +61,7 @@ class EncoderDesc(C.Structure):
                 ("off_word", C.c_int64), ("off_pos", C.c_int64), ("off_type", C.c_int64),
                 ("off_emb_ln_g", C.c_int64), ("off_emb_ln_b", C.c_int64),
                 ("layers_host", C.POINTER(LayerOffsets)), ("seed", C.c_uint64), ("drop_stream_base", C.c_uint32),
-                ("pad", C.c_int32)]
+                ("wgrad_events_n", C.c_int32), ("wgrad_events", C.POINTER(C.c_void_p))]
 
 
 _lib = None

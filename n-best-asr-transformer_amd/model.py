@@ -257,10 +257,12 @@ class NBestSTCModel(nn.Module):
 
     # ---- one training forward + backward (n_best_asr_bert.py:249-264) ---------------------------
     def forward_backward(self, input_ids, labels_f, seg_ids=None, trans_input_ids=None, trans_seg_ids=None,
-                         add_l2_loss=False, mse_grad_scale=1.0, chunks=None, on_chunk_done=None, need_grad=True):
+                         add_l2_loss=False, mse_grad_scale=1.0, chunks=None, on_chunk_done=None, need_grad=True,
+                         accumulate=False):
         """Returns dict(top, bott, final, loss_parts[4] (device), asr_cls, trans_cls).  Gradients of the sum
         BCE(final) + BCE(top) + mean-CE (+ MSE) are left in ``arena.g``.  The transcript pass runs only
-        when its output is used (--add_l2_loss); the reference computes and discards it otherwise (Q4)."""
+        when its output is used (--add_l2_loss); the reference computes and discards it otherwise (Q4).
+        ``accumulate``: add to the gradients already in ``arena.g`` (gradient accumulation) instead of overwriting them."""
         train = self.training
         B, S = input_ids.shape
         H = self.cfg.hidden_size
@@ -272,7 +274,7 @@ class NBestSTCModel(nn.Module):
             St = trans_input_ids.shape[1]
             pt = self._pass(B, St, 1)
             ht = self._encode(pt, trans_input_ids, trans_seg_ids, train)
-        top, bott, fin, loss, dcls, _, _ = self._heads(ha, S, labels_f, need_grad=need_grad, train=train)
+        top, bott, fin, loss, dcls, _, _ = self._heads(ha, S, labels_f, need_grad=need_grad, train=train, accumulate=accumulate)
         dt = None
         if pt is not None:
             dt = torch.empty(B, H, dtype=torch.float32, device=self.device) if need_grad else None
@@ -281,10 +283,10 @@ class NBestSTCModel(nn.Module):
         if need_grad:
             if pt is not None:
                 # transcript pass first (whole stack, no overlap hooks), then the ASR pass accumulates on top
-                self._backward_pass(pt, dt, accumulate=False)
+                self._backward_pass(pt, dt, accumulate=accumulate)
                 self._backward_pass(pa, dcls, accumulate=True, chunks=chunks, on_chunk_done=on_chunk_done)
             else:
-                self._backward_pass(pa, dcls, accumulate=False, chunks=chunks, on_chunk_done=on_chunk_done)
+                self._backward_pass(pa, dcls, accumulate=accumulate, chunks=chunks, on_chunk_done=on_chunk_done)
         self.step_counter += 1
         return dict(top=top, bott=bott, final=fin, loss_parts=loss, asr_cls=ha.view(B, S, H)[:, 0, :],
                     trans_cls=None if ht is None else ht.view(B, St, H)[:, 0, :])

@@ -102,13 +102,18 @@ class GradReducer:
             w.wait()
         self.pending_emb = []
 
+    def reduce_all(self):
+        """exchange the whole gradient arena as it stands, in the bucket order of an overlapped step (used where no backward
+        pass is running to overlap with: gradient-accumulation groups, ranks with an empty slice)"""
+        for lo, hi in reversed(self.chunks):
+            self.layers_ready(lo, hi)
+        self.wait()
+
     def contribute_nothing(self):
         """a rank whose slice of a (short, final) batch is empty still joins every collective of the step, in the same
         order as the ranks that ran a backward pass, with zero gradients"""
         self.arena.g.zero_()
-        for lo, hi in reversed(self.chunks):
-            self.layers_ready(lo, hi)
-        self.wait()
+        self.reduce_all()
 
 
 def train_step(model, optimizer, batch, add_l2_loss=False, add_segment_ids=True, reducer=None, global_batch=None):
@@ -330,22 +335,42 @@ def _prep(raw_in, raw_trans, raw_labels, opt, memory, device):
 
 def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
     """n_best_asr_bert.py:232-294 -> (mean_loss, (p, r, f), acc).  ``data`` = (asr, trans, labels) lists or an
-    EncodedSplit (tokenised once; pass the same object every epoch to reuse it)."""
+    EncodedSplit (tokenised once; pass the same object every epoch to reuse it).
+
+    ``opt.n_accum_steps`` > 1 (n_best_asr_bert.py:522,526,266-280): the loader batch is batchSize / n_accum_steps, gradients
+    of n_accum_steps consecutive micro-batches are summed and the optimizer steps after every n_accum_steps-th one; micro-
+    batches left over at the end of the epoch are dropped by the next epoch's zero_grad, as there.  Under data parallelism
+    only the micro-batch that closes a group exchanges gradients."""
     model.train()
     rank, world = dist_info()
     reducer = GradReducer(model.arena) if (dist.is_available() and dist.is_initialized()) else None
     counts, losses = (0, 0, 0, 0, 0), []
     split = encoded(data, opt, memory)
-    lists = batch_indices(len(split), opt.batchSize, shuffle=shuffle, seed=getattr(opt, "random_seed", 999) + epoch)
+    n_accum = max(1, int(getattr(opt, "n_accum_steps", 1) or 1))
+    lists = batch_indices(len(split), max(1, int(opt.batchSize / n_accum)), shuffle=shuffle, seed=getattr(opt, "random_seed", 999) + epoch)
     for bi, mine, b in Prefetcher(split, lists, model.device, rank, world):
+        first, last = (bi % n_accum == 0), ((bi + 1) % n_accum == 0)
         if not mine:
-            if reducer is not None:
-                reducer.contribute_nothing()
-            opt.optimizer.step()                                     # keeps replicas and schedule positions identical
+            if first:
+                model.arena.g.zero_()
+            if last:
+                if reducer is not None:
+                    reducer.reduce_all()
+                opt.optimizer.step()                                 # keeps replicas and schedule positions identical
             model.step_counter += 1
             continue
-        out = train_step(model, opt.optimizer, b, add_l2_loss=opt.add_l2_loss, add_segment_ids=opt.add_segment_ids, reducer=reducer,
-                         global_batch=len(lists[bi]))
+        if n_accum == 1:
+            out = train_step(model, opt.optimizer, b, add_l2_loss=opt.add_l2_loss, add_segment_ids=opt.add_segment_ids, reducer=reducer,
+                             global_batch=len(lists[bi]))
+        else:
+            seg = b.get("seg") if opt.add_segment_ids else None
+            out = model.forward_backward(b["ids"], b["labels"], seg_ids=seg, trans_input_ids=b.get("tids"), trans_seg_ids=b.get("tseg"),
+                                         add_l2_loss=opt.add_l2_loss, mse_grad_scale=len(mine) / float(len(lists[bi])),
+                                         accumulate=not first)
+            if last:
+                if reducer is not None:
+                    reducer.reduce_all()
+                opt.optimizer.step()
         losses.append((out["loss_parts"], len(mine), len(lists[bi])))
         counts, _ = _host_metrics(model, out, [split.labels[j] for j in mine], memory["idx2label"], counts)
     return _finish(losses, counts, model.device, len(lists))

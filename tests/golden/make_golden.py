@@ -227,6 +227,8 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
     for n, p in om.named_parameters():
         p.grad = ograds[n]
 
+    fx_extra = {}
+
     def floor(a, b):
         d = (a.detach().float() - b.detach().float())
         return np.array([d.abs().max().item(), d.pow(2).mean().sqrt().item()])
@@ -236,8 +238,19 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
                                  torch.cat([bottoms["lin_%d" % t] for t in labels.multi], 1)),
           "floor/asr_cls": floor(sasr, asr_cls), "floor/trans_cls": floor(str_, trans_cls),
           "floor/loss_total": np.array([abs(stotal.item() - total.item()) / abs(total.item())])}
+    import zlib
     for n, g in grads.items():
-        fl["floor/gnorm/" + n] = np.array([abs(sgrads[n].norm().item() - g.norm().item()) / max(g.norm().item(), 1e-30)])
+        gn = max(g.norm().item(), 1e-30)
+        fl["floor/gnorm/" + n] = np.array([abs(sgrads[n].norm().item() - g.norm().item()) / gn])
+        # noise-to-signal of the bf16-storage leg, ||g_sim - g_ref|| / ||g_ref||: by Cauchy-Schwarz it also bounds the
+        # relative norm error; and 512 sampled elements per tensor (indices from a name-keyed legacy numpy stream) so the
+        # GPU test can estimate the SAME statistic for the HIP path without the full reference gradient
+        fl["floor/ns/" + n] = np.array([(sgrads[n] - g).norm().item() / gn])
+        if "word_embeddings" not in n:
+            idx = torch.from_numpy(np.random.RandomState(zlib.crc32(n.encode()) & 0x7FFFFFFF).randint(0, g.numel(), size=512))
+            ref_s, sim_s = g.flatten()[idx], sgrads[n].flatten()[idx]
+            fx_extra["samp/" + n] = ref_s.numpy().astype(np.float32)
+            fl["floor/samp/" + n] = np.array([(sim_s - ref_s).pow(2).mean().sqrt().item(), ref_s.pow(2).mean().sqrt().item()])
     print("   bf16-storage oracle vs reference: top %.2e final %.2e bottoms %.2e asr_cls %.2e loss rel %.2e, worst grad-norm rel %.2e" % (
         fl["floor/top"][0], fl["floor/final"][0], fl["floor/bottoms"][0], fl["floor/asr_cls"][0], fl["floor/loss_total"][0],
         max(v[0] for k, v in fl.items() if k.startswith("floor/gnorm/") and not k.endswith("key.bias"))))
@@ -286,6 +299,7 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
     fl["floor/wordgrad"] = floor(sgrads["bert_encoder.embeddings.word_embeddings.weight"][used, :64],
                                  grads["bert_encoder.embeddings.word_embeddings.weight"][used, :64])
     fx.update(fl)
+    fx.update(fx_extra)
     np.savez_compressed(os.path.join(HERE, "case_%s.npz" % c["name"]), **fx)
     print("   wrote case_%s.npz  loss=%.6f  preds[0]=%s" % (c["name"], total.item(), preds[0]))
 

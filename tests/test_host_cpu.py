@@ -259,3 +259,20 @@ def test_tod_mode_input_builder_matches_reference_fixture():
     for name, side in (("asr", data[0][:8]), ("trans", data[1][:8])):
         ids, seg, lens = inputs.prepare_inputs_for_roberta(side, tok, opt, "cpu")
         assert ids.tolist() == d[name]["ids"] and seg.tolist() == d[name]["seg"] and lens == d[name]["lens"]
+
+
+def test_cli_flag_semantics_follow_the_reference():
+    """--deviceId: 0 = automatic choice (first visible GPU), k > 0 = GPU k-1 (/root/reference/n_best_asr_bert.py:116-126);
+    n_accum_steps = 4 iff --n_layers 12 (:522); choices the reference cannot run, or this build does not build, are refused
+    with a message instead of failing later"""
+    from nbest_amd import cli
+    base = ["--dataset", "dstc2", "--dataroot", "x"]
+    assert cli.parse_arguments(base + ["--deviceId", "0"]).gpu_index == 0
+    assert cli.parse_arguments(base + ["--deviceId", "1"]).gpu_index == 0
+    assert cli.parse_arguments(base + ["--deviceId", "3"]).gpu_index == 2
+    assert cli.parse_arguments(base + ["--deviceId", "0"]).n_accum_steps == 1
+    assert cli.parse_arguments(base + ["--deviceId", "0", "--n_layers", "12"]).n_accum_steps == 4
+    for bad in (["--deviceId", "-1"], ["--deviceId", "0", "--pre_trained_model", "roberta"], ["--deviceId", "0", "--optim_choice", "adamw"],
+                ["--deviceId", "0", "--pre_trained_model", "gpt2"]):
+        with pytest.raises(SystemExit):
+            cli.parse_arguments(base + bad)

@@ -189,7 +189,10 @@ def _attn_ref(qkv, mask, B, S, heads):
 
 @pytest.mark.parametrize("dtype,S", [(torch.float32, 48), (torch.float32, 37), (torch.bfloat16, 128), (torch.bfloat16, 48),
                                      (torch.bfloat16, 37), (torch.bfloat16, 96), (torch.bfloat16, 160), (torch.bfloat16, 256),
-                                     (torch.bfloat16, 201)])
+                                     (torch.bfloat16, 201),
+                                     # long-sequence kernels (256 < S <= 512): ragged last key block, 9 / 10 / 12 / 16 key blocks
+                                     (torch.bfloat16, 257), (torch.bfloat16, 300), (torch.bfloat16, 384), (torch.bfloat16, 512),
+                                     (torch.float32, 300)])
 def test_attention_fwd_bwd(dtype, S):
     B, heads = 3, 4
     H = heads * 64
@@ -225,12 +228,12 @@ def test_attention_fwd_bf16_long(S):
     close("attn_fwd bf16 lse S=%d" % S, lse, lse_ref, 1e-2)
 
 
-@pytest.mark.parametrize("S", [64, 37, 160])
+@pytest.mark.parametrize("S", [64, 37, 160, 300, 333])
 def test_attention_dropout_fwd_bwd_consistent(S):
     """bf16 MFMA and fp32 VALU kernels must draw the SAME mask from (seed, stream); the backward of
     each must be the gradient of its own forward (checked through the fp32 kernel by finite differences
     on a linear functional).  S = 64: one hash per key pair in the bf16 forward; S = 37 (odd): the per-element
-    fallback; S = 160: the five-block backward."""
+    fallback; S = 160: the five-block backward; S = 300 / 333: the long-sequence kernels (pair hash / per-element)."""
     B, heads, p = 2, 2, 0.2
     H = heads * 64
     qkv32 = rnd(B * S, 3 * H, seed=71)

@@ -107,42 +107,74 @@ def test_step_matches_reference_outputs(name, dtype, labels):
         dec = m.decode(out["top"], out["bott"]).cpu().numpy()
         assert np.array_equal(dec, z["decode"]), "decoded label indices differ from the reference"
     named = dict(m.named_parameters())
-    # gradients.  fp32: 2e-3 of each tensor's norm / scale.  bf16: no tensor may be further from the fp32 reference than
-    # 1.5 x the WORST tensor of the bf16-storage oracle on this case (per-tensor floors can be small by chance)
-    # (separately for the encoder tensors and for the small STC heads, whose softmax gradients are far more sensitive)
-    gn_floors = {grp: max(float(z[k][0]) for k in z.files if k.startswith("floor/gnorm/" + grp) and not k.endswith("attention.self.key.bias"))
-                 for grp in ("bert_encoder.", "clf.")}
+    # ---- gradients -------------------------------------------------------------------------------------------------
+    # fp32: 2e-3 of each tensor's norm / scale.
+    # bf16: (a) noise-to-signal.  The golden holds 512 sampled elements of every reference gradient tensor and the rms
+    #   error of the bf16-storage oracle on those SAME elements; the HIP path's rms error there must be within 1.5 x.
+    #   (b) norms.  | ||g|| - ||g_ref|| | <= ||g - g_ref|| (Cauchy-Schwarz), so the relative norm error is bounded by
+    #   1.5 x the oracle leg's noise-to-signal of that tensor - NOT by its own norm error, which is one draw of a random
+    #   sign and is shared by every tensor below the same noisy CLS row (profiles: HIP and oracle leg agree on
+    #   noise-to-signal to ~5 % per tensor while their norm errors differ by a common +1e-3).
+    #   (c) 8 x 64 slices of selected tensors (maximum error) against 2 x the worst relative slice error of the oracle leg.
+    import zlib
+    # "dense": the encoder-layer matrices - thousands of independent draws.  Not dense: tensors under 4096 elements, the
+    # (sparse) embedding tables, and the STC heads, whose gradients are rank-B outer products of B <= 4 noisy rows
+    dense = lambda n: int(np.prod(named[n].shape)) >= 4096 and n.startswith("bert_encoder.encoder.")
+    ns_floor_of = {k[9:]: float(z[k][0]) for k in z.files if k.startswith("floor/ns/") and not k.endswith("attention.self.key.bias")}
+    # the others: their statistic is a handful of draws, so they are held to the worst such tensor of the oracle leg
+    sparse_ns = max(v for n, v in ns_floor_of.items() if not dense(n))
+    sparse_samp = max(float(z[k][0]) / max(float(z[k][1]), 1e-30) for k in z.files if k.startswith("floor/samp/") and not dense(k[11:])
+                      and not k.endswith("attention.self.key.bias"))
+    # a maximum over 512 draws fluctuates more than an rms: slices get 2 x the worst relative slice error of the oracle leg
     gs_floor = max(float(z[k][0]) / max(float(np.abs(z["grad/" + k[11:]]).max()), 1e-30) for k in z.files
                    if k.startswith("floor/grad/") and not k.endswith("attention.self.key.bias"))
     gs_floor = max(gs_floor, float(z["floor/wordgrad"][0]) / max(float(np.abs(z["wordgrad_vals"]).max()), 1e-30))
-    worst_gn = {"bert_encoder.": 0.0, "clf.": 0.0}
+    # pure-noise quantity (mathematically zero), so: the worst layer of the bf16-storage oracle, not the same layer
+    kb_floor = max(float(z[k[6:]]) * (1.0 + float(z[k][0])) for k in z.files
+                   if k.startswith("floor/gnorm/") and k.endswith("attention.self.key.bias"))
+    rows_ns, bad = [], []
     for key in z.files:
         if key.startswith("gnorm/"):
-            g = named[key[6:]].grad
+            name = key[6:]
+            g = named[name].grad
             ref = float(z[key])
             got = g.norm().item()
             if key.endswith("attention.self.key.bias"):
-                # mathematically ZERO (softmax is invariant to a key bias): both sides are rounding noise.  fp32: bound
-                # it against the query-bias gradient of the same layer; bf16: against the noise the bf16-storage oracle
-                # leaves there (its norm = ref * (1 + committed relative floor), the fp32 reference being ~1e-7)
-                qn = named[key[6:].replace(".key.", ".query.")].grad.norm().item()
-                sim = ref * (1.0 + float(z["floor/" + key][0]))
-                _log("%-64s got=%.3e bf16-storage oracle=%.3e query-bias norm=%.3e" % (tag + key[-44:], got, sim, qn))
-                assert got <= (1e-5 * qn if f32 else FLOOR_FACTOR * sim), key
+                # softmax is invariant to a key bias: both sides are rounding noise.  fp32: bound it against the query-bias
+                # gradient of the same layer; bf16: against the noise the bf16-storage oracle leaves there
+                qn = named[name.replace(".key.", ".query.")].grad.norm().item()
+                if got > (1e-5 * qn if f32 else FLOOR_FACTOR * kb_floor):
+                    bad.append((key, got, kb_floor, qn))
                 continue
             rel = abs(got - ref) / max(ref, 1e-6)
-            grp = "clf." if key[6:].startswith("clf.") else "bert_encoder."
-            worst_gn[grp] = max(worst_gn[grp], rel)
-            assert abs(got - ref) <= (2e-3 if f32 else FLOOR_FACTOR * gn_floors[grp]) * max(ref, 1e-6) + (1e-7 if f32 else 1e-4), (key, got, ref)
+            ns_floor = ns_floor_of[name] if dense(name) else sparse_ns
+            if rel > (2e-3 if f32 else FLOOR_FACTOR * ns_floor) + (1e-7 if f32 else 1e-4) / max(ref, 1e-6):
+                bad.append((key, got, ref, ns_floor))
+            if "samp/" + name in z.files:
+                idx = torch.from_numpy(np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF).randint(0, g.numel(), size=512)).cuda()
+                samp = torch.from_numpy(z["samp/" + name]).cuda()
+                err = (g.flatten()[idx].float() - samp).pow(2).mean().sqrt().item()
+                sim_err, sig = float(z["floor/samp/" + name][0]), float(z["floor/samp/" + name][1])
+                if dense(name):
+                    rows_ns.append((err / max(sim_err, 1e-30), err / max(sig, 1e-30), sim_err / max(sig, 1e-30), name))
+                else:
+                    sim_err = sparse_samp * sig
+                lim = 2e-3 * sig + 1e-9 if f32 else FLOOR_FACTOR * sim_err + 2.0 ** -9 * sig
+                if err > lim:
+                    bad.append(("samp/" + name, err, sim_err, sig))
         elif key.startswith("grad/") and not key.endswith("attention.self.key.bias"):
             g = named[key[5:]].grad
             got = g.reshape(-1, g.shape[-1])[:8, :64] if g.dim() > 1 else g[:64]
-            _cmp(tag + key[-52:], got, z[key], rtol=2e-3 if f32 else FLOOR_FACTOR * gs_floor + 2.0 ** -8)
-    for grp in worst_gn:
-        _log(tag + "worst gradient-norm rel err of %-13s %.3e (worst bf16-storage floor %.3e)" % (grp + "*", worst_gn[grp], gn_floors[grp]))
+            _cmp(tag + key[-52:], got, z[key], rtol=2e-3 if f32 else 2.0 * gs_floor + 2.0 ** -8)
+    rows_ns.sort(reverse=True)
+    med = rows_ns[len(rows_ns) // 2]
+    _log(tag + "gradient noise-to-signal on 512 sampled elements per dense tensor (%d tensors), HIP / bf16-storage oracle: median ratio "
+               "%.2f, worst ratio %.2f (%s: HIP %.2e, oracle %.2e)" % (len(rows_ns), med[0], rows_ns[0][0], rows_ns[0][3][-44:],
+                                                                      rows_ns[0][1], rows_ns[0][2]))
+    assert not bad, bad[:4]
     rows = torch.from_numpy(z["wordgrad_rows"]).cuda()
     wg = named["bert_encoder.embeddings.word_embeddings.weight"].grad
-    _cmp(tag + "word-embedding grad rows", wg[rows, :64], z["wordgrad_vals"], rtol=2e-3 if f32 else FLOOR_FACTOR * gs_floor + 2.0 ** -8)
+    _cmp(tag + "word-embedding grad rows", wg[rows, :64], z["wordgrad_vals"], rtol=2e-3 if f32 else 2.0 * gs_floor + 2.0 ** -8)
 
 
 @pytest.mark.parametrize("name", ["bert_L2", "xlmr_L2"])
@@ -228,7 +260,7 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels):
     ref_g = {n: p.grad.detach().clone() for n, p in om.named_parameters() if p.grad is not None}
     f32 = dtype == torch.float32
     fl_top = fl_fin = fl_loss = 0.0
-    fl_gn = {"bert_encoder.": 0.0, "clf.": 0.0}
+    sim_ns = {}
     if not f32:
         # noise floor of THIS case: the same oracle with bf16 storage (oracle/bf16sim.py) against its fp32 self
         for p in om.parameters():
@@ -239,9 +271,8 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels):
         fl_top, fl_fin = (stop - top).abs().max().item(), (sfin - final).abs().max().item()
         fl_loss = abs(stotal.item() - total.item()) / abs(total.item())
         for n, p in om.named_parameters():
-            if n in ref_g and not n.endswith("attention.self.key.bias"):
-                grp = "clf." if n.startswith("clf.") else "bert_encoder."
-                fl_gn[grp] = max(fl_gn[grp], abs(p.grad.norm().item() - ref_g[n].norm().item()) / max(ref_g[n].norm().item(), 1e-6))
+            if n in ref_g:
+                sim_ns[n] = ((p.grad - ref_g[n]).norm() / ref_g[n].norm().clamp_min(1e-30)).item()
     m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0)
     m.load_reference_state(sd)
     m.train()
@@ -256,33 +287,52 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels):
         _cmp_floor(tag + "final", out["final"], final.detach(), fl_fin)
     assert abs(out["loss_parts"].sum().item() - total.item()) <= (1e-4 if f32 else FLOOR_FACTOR * fl_loss + 2.0 ** -9) * abs(total.item())
     named = dict(m.named_parameters())
-    worst = {"bert_encoder.": 0.0, "clf.": 0.0}
+    # gradients: noise-to-signal ||g - g_ref|| / ||g_ref|| per tensor.  fp32: 2e-3.  bf16: within 1.5 x the noise-to-signal of
+    # the bf16-storage oracle on the same tensor (encoder-layer matrices; tensors under 4096 elements, the sparse embedding
+    # tables and the rank-B head gradients are a handful of draws: held to 1.5 x the worst such tensor of the oracle leg)
+    dense = lambda n: ref_g[n].numel() >= 4096 and n.startswith("bert_encoder.encoder.")
+    small_floor = max([v for n, v in sim_ns.items() if not dense(n) and not n.endswith("attention.self.key.bias")] or [0.0])
+    worst = (0.0, "")
     for n, g_ref in ref_g.items():
         if n.endswith("attention.self.key.bias"):
             continue
-        ref = g_ref.norm().item()
-        got = named[n].grad.norm().item()
-        grp = "clf." if n.startswith("clf.") else "bert_encoder."
-        worst[grp] = max(worst[grp], abs(got - ref) / max(ref, 1e-6))
-        rel = 2e-3 if f32 else FLOOR_FACTOR * fl_gn[grp]
-        assert abs(got - ref) <= rel * max(ref, 1e-6) + (1e-6 if f32 else 1e-3), (n, got, ref, rel)
-    _log(tag + "worst grad-norm rel err: encoder %.2e (floor %.2e)  heads %.2e (floor %.2e)" % (
-        worst["bert_encoder."], fl_gn["bert_encoder."], worst["clf."], fl_gn["clf."]))
+        ns = ((named[n].grad.float().cpu() - g_ref).norm() / g_ref.norm().clamp_min(1e-30)).item()
+        if f32:
+            lim = 2e-3
+        else:
+            lim = FLOOR_FACTOR * (sim_ns[n] if dense(n) else small_floor) + 1e-3
+            worst = max(worst, (ns / max(sim_ns[n], 1e-30), n))
+        assert ns <= lim, (n, ns, lim, sim_ns.get(n))
+    if not f32:
+        _log(tag + "worst gradient noise-to-signal ratio HIP / bf16-storage oracle: %.2f (%s)" % worst)
     if f32:
         dec = stc.decode_indices(top.detach(), {k: v.detach() for k, v in bottoms.items()}, labels.top2bottom, labels.idx2label)
         assert torch.equal(m.decode(out["top"], out["bott"]).cpu().long(), dec)
 
 
 def test_too_long_sequence_fails_loudly(labels):
+    """S beyond the position table (512 for BERT): RuntimeError before any kernel is enqueued (the reference would index
+    past the table, /root/reference/utils/bert_xlnet_inputs.py:87-94 never truncates)"""
     import nbest_amd  # noqa: F401
     from nbest_amd import config as ncfg, synth
     from nbest_amd.model import NBestSTCModel
     cfg = ncfg.bert_base(num_hidden_layers=1, vocab_size=3000)
     m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.bfloat16)
     m.load_reference_state(synth.model_state(cfg, labels, seed=1))
-    ids = torch.randint(5, 2000, (1, 300), device="cuda")
-    with pytest.raises(RuntimeError, match="S=300"):
+    ids = torch.randint(5, 2000, (1, 520), device="cuda")
+    with pytest.raises(RuntimeError, match="S=520"):
         m.forward_backward(ids, torch.zeros(1, labels.n_bottom, device="cuda"))
+
+
+@pytest.mark.parametrize("B,S,St", [(2, 300, 40), (1, 384, 64), (1, 512, 300)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_long_sequences_match_oracle(B, S, St, dtype, labels):
+    """256 < S <= 512 (BERT's position table ends at 512; the shipped valid split reaches > 256 tokens once words are split
+    into word pieces): the long-sequence attention kernels, whole step against the oracle - incl. a 300-token transcript"""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    _check_vs_oracle(cfg, B, S, St, dtype, labels)
 
 
 def test_activation_stash_is_bounded_over_varying_shapes(labels):
@@ -318,6 +368,35 @@ def test_activation_stash_is_bounded_over_varying_shapes(labels):
         assert torch.cuda.memory_allocated() <= base + (1 << 20), (B, S, torch.cuda.memory_allocated(), base)
     assert len(seen) >= 20
     assert len(m._stash) == 2 and len(m._passes) >= 20   # two stashes (ASR / transcript pass), one small descriptor per shape
+
+
+def test_gradient_accumulation_equals_whole_batch(labels):
+    """n_accum_steps (/root/reference/n_best_asr_bert.py:266,522): gradients of micro-batches are summed in the arena
+    (accumulate=True) - equal to the gradient of the concatenated batch, the losses being sum-reduced; the MSE term (a mean
+    over the batch) is weighted by the micro-batch share"""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.float32, dropout=0.0)
+    m.load_reference_state(synth.model_state(cfg, labels, seed=9))
+    m.train()
+    b = synth.nbest_batch(cfg, labels, 6, 40, n_best=4, seed=5, ragged=True, trans_len=12)
+    t = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    sl = lambda lo, hi: {k: v[lo:hi].contiguous() for k, v in t.items()}
+    run = lambda x, **kw: m.forward_backward(x["ids"], x["labels"], seg_ids=x["seg"], trans_input_ids=x["tids"], trans_seg_ids=x["tseg"],
+                                             add_l2_loss=True, **kw)
+    run(t)
+    whole = m.arena.g.clone()
+    run(sl(0, 4), mse_grad_scale=4 / 6)
+    run(sl(4, 6), mse_grad_scale=2 / 6, accumulate=True)
+    lo, hi = m.arena.by_name["bert_encoder.pooler.dense.weight"].offset, m.arena.by_name["bert_encoder.pooler.dense.bias"].offset
+    a = m.arena
+    for s_ in a.slots:
+        if "pooler" in s_.name or s_.name.endswith("attention.self.key.bias"):
+            continue
+        x, y = a.view(m.arena.g, s_.name), a.view(whole, s_.name)
+        assert (x - y).abs().max().item() <= 2e-5 * max(y.abs().max().item(), 1e-6), s_.name
 
 
 def test_training_step_is_hip_graph_capturable(labels):

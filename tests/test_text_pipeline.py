@@ -77,6 +77,45 @@ def test_train_and_eval_epoch_match_reference(labels):
     assert fp.getvalue() == str(z["eval_lines"])                          # raw <=> pred <=> gold lines, byte for byte
 
 
+@pytest.mark.gpu
+def test_utterance_longer_than_256_tokens_runs_untruncated(labels):
+    """The reference never truncates (utils/bert_xlnet_inputs.py:87-94; --max_seq_len is ignored there): an utterance whose
+    n-best list tokenises to more than 256 positions must train and evaluate in the default bf16 path without
+    --max_seq_len.  Three real utterances + one whose hypotheses are those of five lines put together (S in (256, 512]);
+    the bf16 step agrees with the fp32 parity path of the same build on the same batch."""
+    from nbest_amd.model import NBestSTCModel
+    from nbest_amd.optim import HipBertAdam
+    z, vocab, data = _load()
+    asr, trans, lab = [list(x[:3]) for x in data]
+    hyps = []
+    for a in data[0][:5]:                                   # five n-best lists in one: 425 tokens
+        hyps += a[a.index("[USR]") + 1:] + ["[SEP]"]
+    head = data[0][0][:data[0][0].index("[USR]") + 1]
+    asr.append(head + hyps[:-1])
+    trans.append(data[1][0])
+    lab.append(data[2][0])
+    tok = inputs.WordPieceTokenizer(vocab)
+    label2idx = json.loads(str(z["label2idx"]))
+    memory = dict(label2idx=label2idx, idx2label=labels.idx2label)
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=len(vocab), hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0)
+        m.load_reference_state(synth.model_state(cfg, labels, seed=3))
+        opt = types.SimpleNamespace(batchSize=4, tokenizer=tok, pre_trained_model="bert", tod_pre_trained_model=None,
+                                    without_system_act=False, add_l2_loss=True, add_segment_ids=True, max_seq_len=None)
+        opt.optimizer = HipBertAdam(m, lr=5e-4, bert_lr=3e-5, warmup=0.1, t_total=10)
+        split = trainer.EncodedSplit((asr, trans, lab), opt, memory)
+        S = max(len(r[0]) for r in split.rows)
+        assert 256 < S <= 512, S
+        loss, prf, acc = trainer.train_epoch(m, split, opt, memory, shuffle=False)
+        eloss, eprf, eacc, cases = trainer.eval_epoch(m, split, opt, memory)
+        assert np.isfinite(loss) and np.isfinite(eloss) and len(cases) == 4
+        res[dtype] = (loss, eloss)
+    assert abs(res[torch.bfloat16][0] - res[torch.float32][0]) <= 1e-2 * abs(res[torch.float32][0]), res
+    assert abs(res[torch.bfloat16][1] - res[torch.float32][1]) <= 2e-2 * abs(res[torch.float32][1]), res
+
+
 def test_coverage_sampler_matches_reference():
     """--coverage: same rows in the same order as the reference's pandas-based stratified sampler
     (digests produced by tests/golden/make_golden.py from /root/reference/utils/dataset/tod_asr_util.py)."""

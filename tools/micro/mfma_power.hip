@@ -23,6 +23,20 @@ __global__ __launch_bounds__(512) void k(float* sink, int reps) {
       for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[i & 3], av[i >> 2], acc[i], 0, 0, 0);
     }
     for (int i = 0; i < 32; ++i) s += acc[i][0];
+  } else if (SHAPE == 33) {   // 32x32x16, random operands, 4 x 2 register tile of 32x32 blocks, two k-steps (same MACs per pass as 17)
+    bf16x8 av[4][2], bv[2][2];
+    uint32_t h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int q = 0; q < 4; ++q) for (int t = 0; t < 2; ++t) for (int i = 0; i < 8; ++i) { h = h * 1664525u + 1013904223u; av[q][t][i] = (__bf16)(((int)(h >> 16) & 0xFFFF) / 65536.0f - 0.5f); }
+    for (int q = 0; q < 2; ++q) for (int t = 0; t < 2; ++t) for (int i = 0; i < 8; ++i) { h = h * 1664525u + 1013904223u; bv[q][t][i] = (__bf16)(((int)(h >> 16) & 0xFFFF) / 65536.0f - 0.5f); }
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[i & 1][t], av[i >> 1][t], acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 8; ++i) s += acc[i][0];
   } else if (SHAPE == 16) {
     f32x4 acc[32];
     for (int i = 0; i < 32; ++i) acc[i] = f32x4{0, 0, 0, 0};
@@ -67,5 +81,7 @@ int main() {
   run<16>("v_mfma_f32_16x16x32_bf16", sink);
   run<32>("v_mfma_f32_32x32x16_bf16", sink);
   run<17>("v_mfma_f32_16x16x32_bf16, random operands, 8x4 register tile", sink);
+  run<33>("v_mfma_f32_32x32x16_bf16, random operands, 4x2 register tile", sink);
+  run<17>("v_mfma_f32_16x16x32_bf16, random operands, 8x4 register tile (again)", sink);
   return 0;
 }
