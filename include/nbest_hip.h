@@ -11,7 +11,8 @@
  *     name ends in _host; the library never allocates, never synchronises, never touches the default
  *     stream: work is enqueued on `stream` (a hipStream_t passed as void*).
  *   - returns NBEST_OK (0) or a negative NBEST_ERR_*; nbest_last_error() gives the message
- *     (thread-local).  No global mutable state: entry points are re-entrant.
+ *     (thread-local).  No global mutable state and no environment variables: entry points are re-entrant and the
+ *     shipped library has one code path per shape (experiment switches exist only in `make diag` builds).
  *   - dtype: NBEST_F32 or NBEST_BF16 = type of activations, weight matrices and embedding tables.
  *     Biases, LayerNorm parameters, statistics, losses, gradients of parameters and optimizer state
  *     are always fp32.

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   }
 }
 
+#ifdef NBEST_EXPERIMENTS   // first-generation backward: kept for A/B measurements only
 // backward, Sp = 32*NKB <= 128.  LDS: Qt | Kt | Vt | dOt ([Sp][64] bf16 each) | dSb [Sp][128] bf16 | lse | delta | madd
 template <int NKB>
 __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
@@ -453,6 +454,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16* __restri
     store_tile(Vt, r0, dv0, dv1, lane, g + 2 * H, ld, S - r0);
   }
 }
+
+#endif  // NBEST_EXPERIMENTS
 
 // ---- backward, second structure: S <= 256, small LDS footprint -----------------------------------------
 // One wave per 32-key block (4 waves for S <= 128, 8 for S <= 256).  LDS: Qt | Kt | dOt ([Sp][64] bf16) and a
@@ -936,7 +939,9 @@ static void launch_bwd2(const bf16* qkv, const uint8_t* mask, const bf16* ctx, c
 }
 
 static size_t fwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * 256 + (size_t)nkb * 32 * 4 + 4 * 4096; }
+#ifdef NBEST_EXPERIMENTS
 static size_t bwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * (4 * 128 + 256) + (size_t)nkb * 32 * 12; }
+#endif
 
 template <int NKB>
 static void launch_fwd(const bf16* qkv, const uint8_t* mask, bf16* ctx, float* lse, int B, int S, int heads, int H, float scale,
@@ -945,6 +950,7 @@ static void launch_fwd(const bf16* qkv, const uint8_t* mask, bf16* ctx, float* l
   (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   attn_fwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d);
 }
+#ifdef NBEST_EXPERIMENTS
 template <int NKB>
 static void launch_bwd(const bf16* qkv, const uint8_t* mask, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv,
                        float* colpart, int B, int S, int heads, int H, float scale, DropCfg d, hipStream_t st) {
@@ -952,6 +958,7 @@ static void launch_bwd(const bf16* qkv, const uint8_t* mask, const bf16* ctx, co
   (void)hipFuncSetAttribute((const void*)attn_bwd_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   attn_bwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d);
 }
+#endif
 
 static int check_common(const char* who, int B, int S, int heads, int d, int dtype) {
   NB_CHECK(B > 0 && S > 0 && heads > 0, NBEST_ERR_SHAPE, "%s: bad shape", who);
@@ -1034,17 +1041,21 @@ extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, con
     if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
     return NBEST_OK;
   }
-  // NBEST_ATTN_BWD=1 selects the first structure (everything in LDS, S <= 128) for A/B measurements
+#ifdef NBEST_EXPERIMENTS
+  // experiment builds (`make diag`): NBEST_ATTN_BWD=1 selects the first structure (everything in LDS, S <= 128) for A/B runs
   static const int old_structure = [] { const char* e = getenv("NBEST_ATTN_BWD"); return (e && e[0] == '1') ? 1 : 0; }();
   if (old_structure && nkb <= 4) {
 #define F(N) case N: launch_bwd<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st); break;
     switch (nkb) { F(1) F(2) F(3) F(4) }
 #undef F
-  } else {
-#define F(N) case N: launch_bwd2<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st); break;
-    switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
-#undef F
+    NB_LAUNCH_CHECK();
+    if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
+    return NBEST_OK;
   }
+#endif
+#define F(N) case N: launch_bwd2<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st); break;
+  switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
+#undef F
   NB_LAUNCH_CHECK();
   if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
   return NBEST_OK;

@@ -13,7 +13,7 @@
 //                the QKV / FFN weight gradients (split-K).
 //       256x128 / 128x128, 4 waves, 2 workgroups/CU  plain ring / ring with double-buffered fragments
 //                (kept for the fp32-master fallback layouts and for experiments; v1 wins on N = 768).
-//       gemm2p_kernel  persistent ping-pong (opt-in), see there.
+//       gemm2p_kernel  persistent ping-pong: experiment builds only (`make diag`, -DNBEST_EXPERIMENTS), see there.
 //   * LDS images (LDS-DMA is lane-linear, so the swizzle lives in the SOURCE address and the read
 //     address): k-contiguous operand [rows][32 k], 64-B rows: chunk ^= (-(row>>2))&3 (conflict-free
 //     for the 16-lane groups of ds_read_b128 even though a group mixes two k-chunks);
@@ -23,7 +23,8 @@
 //   * epilogue as v1 (fp32 restage through wave-private LDS into a row-contiguous layout, 16-byte
 //     whole-line I/O, fast erf) but in 32-row chunks, with the residual / pre-activation rows of the
 //     next chunk prefetched while the current one is processed.
-//   * -DNBEST_DIAG=<mask> builds are timing-only ablations / cycle-stamp builds (tools/, profiles/README.md).
+//   * -DNBEST_DIAG=<mask> (`make diag DIAG=<mask>`) builds are timing-only ablations / cycle-stamp builds (tools/,
+//     profiles/README.md); the shipped library is built with NBEST_DIAG = 0 and without NBEST_EXPERIMENTS.
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -452,6 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   }
 }
 
+#ifdef NBEST_EXPERIMENTS
 // LDS / global accesses that the wait-count pass must not see (it would drain the in-flight LDS-DMA ring, and every
 // store with it, in front of each of them); the caller orders them with explicit s_waitcnt.
 __device__ __forceinline__ void lds_write_b128_asm(const void* addr, f32x4 v) {
@@ -643,6 +645,8 @@ __global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
   }
 }
 
+#endif  // NBEST_EXPERIMENTS
+
 __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float* __restrict__ slab, float* __restrict__ C, int64_t MN,
                                                              int64_t N, int64_t ldc, int splits, int accumulate) {
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * blockDim.x * 4) {
@@ -660,12 +664,14 @@ struct Plan {
   int64_t kps;
 };
 
+// The shipped library has ONE code path per shape and reads no environment.  `make diag` (-DNBEST_EXPERIMENTS) builds
+// csrc/diag/libnbest_diag.so, in which NBEST_PERSISTENT=1 selects the persistent kernel and NBEST_TILE=256x256 | 256x128 |
+// 128x256 | 128x128 forces a tile (tools/ load it through NBEST_LIB).
+#ifdef NBEST_EXPERIMENTS
 static bool persistent_enabled() {
   static const bool v = [] { const char* e = getenv("NBEST_PERSISTENT"); return e && *e == '1'; }();
   return v;
 }
-
-// NBEST_TILE=256x256 | 256x128 | 128x128 forces a tile (experiments); default: per-shape choice
 static int forced_tile() {
   static const int v = [] {
     const char* e = getenv("NBEST_TILE");
@@ -678,6 +684,10 @@ static int forced_tile() {
   }();
   return v;
 }
+#else
+static constexpr bool persistent_enabled() { return false; }
+static constexpr int forced_tile() { return 0; }
+#endif
 
 static Plan make_plan(const nbest_gemm_args* a) {
   Plan pl;
@@ -803,6 +813,7 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
     if (!a->trans_a && !a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, true>(p, epi, grid, st);
     else rc = launch2<128, 256, 2, 4, 4, true, true>(p, epi, grid, st);
+#ifdef NBEST_EXPERIMENTS
   } else if (pl.bm == 256 && pl.bn == 256 && !a->trans_a && !a->trans_b && pl.splits == 1 && !p.colpart && a->K % BK == 0 &&
              a->K >= 3 * BK && grid > 256 && (epi == NBEST_EPI_NONE || epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU) &&
              persistent_enabled()) {
@@ -817,6 +828,7 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
 #undef LP
     NB_LAUNCH_CHECK();
     rc = NBEST_OK;
+#endif
   } else if (pl.bm == 256 && pl.bn == 256) {
     if (!a->trans_a && !a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, true>(p, epi, grid, st);

@@ -126,11 +126,16 @@ size_t nbest_gemm_bf16_v2_ws_bytes(const nbest_gemm_args* a);
 int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st);
 bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a);
 
-// NBEST_GEMM=v1 / v2 forces one generation (A/B measurements); default: per-shape choice
+// per-shape choice of the kernel generation; experiment builds (`make diag`, -DNBEST_EXPERIMENTS) can force one with
+// NBEST_GEMM=v1 / v2 for A/B measurements - the shipped library reads no environment
+#ifdef NBEST_EXPERIMENTS
 static int forced_gen() {
   static const int v = [] { const char* e = getenv("NBEST_GEMM"); return (e && e[0] == 'v' && (e[1] == '1' || e[1] == '2')) ? e[1] - '0' : 0; }();
   return v;
 }
+#else
+static constexpr int forced_gen() { return 0; }
+#endif
 static bool use_v2(const nbest_gemm_args* a) {
   const int f = forced_gen();
   return f == 2 || (f == 0 && nbest_gemm_bf16_v2_wins(a));

@@ -65,10 +65,27 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class GradReducer:
-    """bucketed asynchronous SUM all-reduce of slices of the flat gradient arena"""
+def _all_gather_flat(out, inp):
+    """async all-gather of equal-sized tensors into one flat buffer (RCCL: the fused collective; gloo - CPU tests and the
+    one-GPU rehearsal - gathers into views of it)"""
+    if dist.get_backend() == "nccl":
+        return dist.all_gather_into_tensor(out, inp, async_op=True)
+    n = inp.shape[0]
+    return dist.all_gather([out[r * n:(r + 1) * n] for r in range(dist.get_world_size())], inp, async_op=True)
 
-    def __init__(self, arena, n_chunks=6):
+
+class GradReducer:
+    """bucketed asynchronous SUM all-reduce of slices of the flat gradient arena.
+
+    Word-embedding table: with a 250 002-row vocabulary (XLM-R: 768 MB of fp32 gradient, 1 GB for the large model) only the
+    <= B_local * (S + S_t) rows of tokens in the rank's shard are non-zero, and the table is the LAST bucket (the embedding
+    backward is the last kernel), so nothing hides it.  ``sparse_word_grad`` (default: tables over 256 MB, i.e. XLM-R but not
+    BERT's 94 MB) exchanges ``(row ids, row values)`` instead: every rank all-gathers its touched rows (32 x 128 tokens:
+    <= 12.6 MB per rank instead of 768 MB through the all-reduce) and rebuilds the summed table locally - own rows zeroed,
+    then every rank's rows added in rank order, so all replicas perform the same additions in the same order and stay
+    bit-identical.  Position / token-type tables and the embedding LayerNorm stay in a (small) dense bucket."""
+
+    def __init__(self, arena, n_chunks=6, sparse_word_grad=None):
         self.arena = arena
         self.rank, self.world = dist_info()
         L = len(arena.layer_range)
@@ -77,7 +94,61 @@ class GradReducer:
         self.chunks = [(edges[i], edges[i + 1]) for i in range(n_chunks) if edges[i + 1] > edges[i]]
         self.pending = []
         self.pending_emb = []
+        ws = arena.by_name["bert_encoder.embeddings.word_embeddings.weight"]
+        self.word = (ws.offset, ws.offset + ws.numel, ws.shape)
+        self.sparse = (ws.numel * 4 > (256 << 20)) if sparse_word_grad is None else bool(sparse_word_grad)
+        self._tok = None          # (unique row ids of this rank's shard, async count exchange) of the running step
+        self._sparse = None
 
+    # ---- sparse word-embedding rows ------------------------------------------------------------------------------------
+    def set_step_tokens(self, *id_tensors, rows=None):
+        """call BEFORE the step's forward: ``rows`` = sorted unique token ids of this rank's shard (a device tensor whose
+        size the host already knows - EncodedSplit / bench.py build it on the host, so nothing synchronises), or the
+        token-id tensors themselves (then the unique rows are computed on the device, which costs one host
+        synchronisation at the start of the step).  The per-rank row counts are exchanged asynchronously right away."""
+        if not (self.sparse and self.world > 1):
+            return
+        dev = self.arena.device
+        if rows is None:
+            toks = [t.reshape(-1) for t in id_tensors if t is not None and t.numel()]
+            rows = torch.unique(torch.cat(toks)) if toks else torch.empty(0, dtype=torch.long, device=dev)
+        n = torch.tensor([rows.numel()], dtype=torch.long, device=dev)
+        counts = torch.zeros(self.world, dtype=torch.long, device=dev)
+        work = _all_gather_flat(counts, n)
+        self._tok = (rows, counts, work)
+
+    def _start_sparse(self):
+        rows, counts, work = self._tok
+        work.wait()
+        cnt = counts.tolist()
+        cap = max(max(cnt), 1)
+        lo, hi, shape = self.word
+        G = self.arena.g[lo:hi].view(shape)
+        dev = G.device
+        ids = torch.full((cap,), -1, dtype=torch.long, device=dev)
+        vals = torch.zeros(cap, shape[1], dtype=G.dtype, device=dev)
+        if rows.numel():
+            ids[:rows.numel()] = rows
+            vals[:rows.numel()] = G.index_select(0, rows)
+        all_ids = torch.empty(self.world * cap, dtype=torch.long, device=dev)
+        all_vals = torch.empty(self.world * cap, shape[1], dtype=G.dtype, device=dev)
+        w1 = _all_gather_flat(all_ids, ids)
+        w2 = _all_gather_flat(all_vals, vals)
+        self._sparse = (w1, w2, rows, cnt, cap, all_ids, all_vals, G)
+        self._tok = None
+
+    def _finish_sparse(self):
+        w1, w2, rows, cnt, cap, all_ids, all_vals, G = self._sparse
+        w1.wait()
+        w2.wait()
+        if rows.numel():
+            G.index_fill_(0, rows, 0.0)
+        for r in range(self.world):                                     # the same additions in the same order on every rank
+            if cnt[r]:
+                G.index_add_(0, all_ids[r * cap:r * cap + cnt[r]], all_vals[r * cap:r * cap + cnt[r]])
+        self._sparse = None
+
+    # ---- dense buckets -------------------------------------------------------------------------------------------------
     def _launch(self, lo, hi, last=False):
         if dist.is_available() and dist.is_initialized() and hi > lo:
             w = dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
@@ -87,8 +158,14 @@ class GradReducer:
         if not self.pending and not self.pending_emb:
             self._launch(*self.arena.heads_range)    # head gradients were complete before the encoder backward began
         self._launch(self.arena.layer_range[l_lo][0], self.arena.layer_range[l_hi - 1][1])
-        if l_lo == 0:
-            self._launch(*self.arena.emb_range, last=True)   # embedding backward is the last kernel of the chunk
+        if l_lo == 0:                                # embedding backward is the last kernel of the chunk
+            if self.sparse and self.world > 1:
+                if self._tok is None:
+                    raise RuntimeError("GradReducer: sparse word-embedding exchange needs set_step_tokens() before the step")
+                self._launch(self.word[1], self.arena.emb_range[1], last=True)
+                self._start_sparse()
+            else:
+                self._launch(*self.arena.emb_range, last=True)
 
     def wait_layers(self):
         """heads + encoder layers exchanged (the embedding tables may still be in flight)"""
@@ -101,6 +178,8 @@ class GradReducer:
         for w in self.pending_emb:
             w.wait()
         self.pending_emb = []
+        if self._sparse is not None:
+            self._finish_sparse()
 
     def reduce_all(self):
         """exchange the whole gradient arena as it stands, in the bucket order of an overlapped step (used where no backward
@@ -113,6 +192,7 @@ class GradReducer:
         """a rank whose slice of a (short, final) batch is empty still joins every collective of the step, in the same
         order as the ranks that ran a backward pass, with zero gradients"""
         self.arena.g.zero_()
+        self.set_step_tokens()
         self.reduce_all()
 
 
@@ -127,6 +207,8 @@ def train_step(model, optimizer, batch, add_l2_loss=False, add_segment_ids=True,
     # MSE is a MEAN over B_global x H (n_best_asr_bert.py:574): the local kernel differentiates the mean over its own
     # B_local rows, so after the SUM all-reduce the term needs the weight B_local / B_global (= 1/world for equal shards)
     mse_scale = b_local / float(global_batch) if global_batch else 1.0 / world
+    if reducer is not None:
+        reducer.set_step_tokens(batch["ids"], batch.get("tids") if add_l2_loss else None, rows=batch.get("word_rows"))
     out = model.forward_backward(batch["ids"], batch["labels"], seg_ids=seg, trans_input_ids=batch.get("tids"),
                                  trans_seg_ids=batch.get("tseg"), add_l2_loss=add_l2_loss, mse_grad_scale=mse_scale,
                                  chunks=chunks, on_chunk_done=reducer.layers_ready if reducer is not None else None)
@@ -257,7 +339,10 @@ class EncodedSplit:
         ids, seg, _ = collate([self.rows[j] for j in idx], self.pad, pin)
         tids, tseg, _ = collate([self.trows[j] for j in idx], self.pad, pin)
         y = self.y[torch.as_tensor(idx, dtype=torch.long)]
-        return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=y.pin_memory() if pin else y)
+        # rows of the word-embedding table this batch touches (sparse gradient exchange under data parallelism)
+        rows = torch.unique(torch.cat([ids.reshape(-1), tids.reshape(-1)]))
+        return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=y.pin_memory() if pin else y,
+                    word_rows=rows.pin_memory() if pin else rows)
 
 
 def encoded(data, opt, memory):
@@ -348,13 +433,17 @@ def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
     split = encoded(data, opt, memory)
     n_accum = max(1, int(getattr(opt, "n_accum_steps", 1) or 1))
     lists = batch_indices(len(split), max(1, int(opt.batchSize / n_accum)), shuffle=shuffle, seed=getattr(opt, "random_seed", 999) + epoch)
+    group_rows = []                                                  # word-table rows touched by the running accumulation group
     for bi, mine, b in Prefetcher(split, lists, model.device, rank, world):
         first, last = (bi % n_accum == 0), ((bi + 1) % n_accum == 0)
+        if first:
+            group_rows = []
         if not mine:
             if first:
                 model.arena.g.zero_()
             if last:
                 if reducer is not None:
+                    reducer.set_step_tokens(*group_rows)
                     reducer.reduce_all()
                 opt.optimizer.step()                                 # keeps replicas and schedule positions identical
             model.step_counter += 1
@@ -367,8 +456,10 @@ def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
             out = model.forward_backward(b["ids"], b["labels"], seg_ids=seg, trans_input_ids=b.get("tids"), trans_seg_ids=b.get("tseg"),
                                          add_l2_loss=opt.add_l2_loss, mse_grad_scale=len(mine) / float(len(lists[bi])),
                                          accumulate=not first)
+            group_rows.append(b["word_rows"])
             if last:
                 if reducer is not None:
+                    reducer.set_step_tokens(*group_rows)
                     reducer.reduce_all()
                 opt.optimizer.step()
         losses.append((out["loss_parts"], len(mine), len(lists[bi])))

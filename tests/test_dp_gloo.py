@@ -71,6 +71,43 @@ def _worker(rank, world, port, q):
     dist.broadcast(ref0, src=0)
     for lo_, hi_ in [a.heads_range, a.emb_range] + [(a.layer_range[l][0], a.layer_range[l][1]) for l in range(len(a.layer_range))]:
         ok = ok and torch.equal(a.g[lo_:hi_], ref0[lo_:hi_])
+    # sparse exchange of the word-embedding gradient (XLM-R's 250 002-row table under DP): rows touched by the rank's own
+    # tokens travel as (ids, values); the rebuilt table equals the dense SUM and is bit-identical on both ranks
+    red3 = trainer.GradReducer(a, n_chunks=2, sparse_word_grad=True)
+    ws = a.by_name["bert_encoder.embeddings.word_embeddings.weight"]
+    V, Hd = ws.shape
+    gen = torch.Generator().manual_seed(100 + rank)
+    toks = torch.randint(0, V, (3 + rank, 17), generator=gen)               # ragged across ranks, overlapping rows
+    toks[0, :4] = torch.tensor([5, 6, 7, 5])                                # rows both ranks touch, one of them twice
+    a.g.copy_(torch.randn(a.total, generator=gen))
+    G = a.g[ws.offset:ws.offset + ws.numel].view(V, Hd)
+    dense_rows = torch.zeros(V, dtype=torch.bool)
+    dense_rows[toks.reshape(-1)] = True
+    G[~dense_rows] = 0                                                      # what the embedding backward leaves: only touched rows
+    mine = a.g.clone()
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    want3 = both[0] + both[1]
+    red3.set_step_tokens(toks)                                              # device-side unique (no host-built row list)
+    for lo_, hi_ in reversed(red3.chunks):
+        red3.layers_ready(lo_, hi_)
+    red3.wait()
+    for lo_, hi_ in [a.emb_range, a.heads_range] + [(a.layer_range[l][0], a.layer_range[l][1]) for l in range(len(a.layer_range))]:
+        ok = ok and torch.allclose(a.g[lo_:hi_], want3[lo_:hi_], atol=1e-6)
+    got3 = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got3, a.g.clone())
+    ok = ok and torch.equal(got3[0][:ws.numel], got3[1][:ws.numel])         # replicas bit-identical
+    # the same through a host-built row list (what EncodedSplit / bench.py hand over), and a rank with no tokens at all
+    a.g.copy_(mine)
+    if rank == 0:
+        red3.set_step_tokens(rows=torch.unique(toks.reshape(-1)))
+        for lo_, hi_ in reversed(red3.chunks):
+            red3.layers_ready(lo_, hi_)
+        red3.wait()
+        ok = ok and torch.allclose(a.g[:ws.numel], mine[:ws.numel], atol=0)   # rank 1 contributed zeros
+    else:
+        red3.contribute_nothing()
+        ok = ok and torch.equal(a.g[:ws.numel], both[0][:ws.numel])
     # eval cases: every rank holds its slice of each batch; merged list = dataset order on every rank
     mine = [(b, rank, [("b%d" % b, "r%d" % rank, i) for i in range(2 - rank + b % 2)]) for b in range(3)]
     merged = trainer.merge_cases(mine)

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 LOG = os.path.join(ROOT, "gpurun_out", "dp_equivalence.log")
 
 
-def _worker(rank, world, port, B, q):
+def _worker(rank, world, port, B, sparse, q):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -57,7 +57,8 @@ def _worker(rank, world, port, B, q):
         # data parallel: every rank starts from a DIFFERENT seed; the broadcast makes rank 0's parameters win
         m, opt = build(seed=5 + rank)
         broadcast_parameters(m)
-        red = GradReducer(m.arena, n_chunks=2)
+        red = GradReducer(m.arena, n_chunks=2, sparse_word_grad=sparse)
+        red.set_step_tokens(shard(batches[0])["ids"], shard(batches[0])["tids"])
         mine = shard(batches[0])
         m.forward_backward(mine["ids"], mine["labels"], seg_ids=mine["seg"], trans_input_ids=mine["tids"], trans_seg_ids=mine["tseg"],
                            add_l2_loss=True, mse_grad_scale=(hi - lo) / B, chunks=red.chunks, on_chunk_done=red.layers_ready)
@@ -110,12 +111,13 @@ def _worker(rank, world, port, B, q):
         q.put((rank, dict(error=traceback.format_exc() + repr(e))))
 
 
-@pytest.mark.parametrize("world,B", [(2, 5), (3, 7)])
-def test_dp_step_equals_single_process(world, B):
+@pytest.mark.parametrize("world,B,sparse", [(2, 5, False), (3, 7, True)])
+def test_dp_step_equals_single_process(world, B, sparse):
+    """sparse: the word-embedding gradient travels as (row ids, row values) instead of through the dense all-reduce"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29620 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, sparse, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in procs)
@@ -126,7 +128,8 @@ def test_dp_step_equals_single_process(world, B):
     r0 = res[0]
     os.makedirs(os.path.dirname(LOG), exist_ok=True)
     with open(LOG, "a") as f:
-        f.write("world %d, batch %d (uneven shards), fp32, 4 layers, lr 1e-3, 3 BertAdam steps\n" % (world, B))
+        f.write("world %d, batch %d (uneven shards), fp32, 4 layers, lr 1e-3, 3 BertAdam steps, word-embedding gradient exchange: %s\n" % (
+            world, B, "sparse rows" if sparse else "dense all-reduce"))
         f.write("  reduced-shard gradient vs whole-batch gradient: max relative difference %.2e (bound 2e-5)\n" % r0["gerr"])
         f.write("  parameters: mean |DP - single| %.2e (bound 2e-6), max %.2e; replicas bit-identical: %s\n" % (
             r0["mean_err"], r0["max_err"], all(res[r]["same"] for r in range(world))))

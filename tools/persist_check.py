@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""correctness + timing of the persistent ping-pong GEMM (NBEST_PERSISTENT=1) against the per-tile kernel and torch"""
+"""correctness + timing of the persistent ping-pong GEMM (experiment build: make -C .../csrc diag; NBEST_LIB=.../diag/libnbest_diag.so NBEST_PERSISTENT=1) against the per-tile kernel and torch"""
 import os
 import sys
 import torch

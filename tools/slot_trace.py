@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """cycle stamps of the ping-pong slots of workgroup 0 (diagnostic build -DNBEST_DIAG=32):
-NBEST_LIB=n-best-asr-transformer_amd/csrc/diag/libnbest_d32.so python tools/slot_trace.py"""
+make -C n-best-asr-transformer_amd/csrc diag DIAG=32 && NBEST_LIB=n-best-asr-transformer_amd/csrc/diag/libnbest_diag32.so python tools/slot_trace.py"""
 import os
 import sys
 import numpy as np
