@@ -240,15 +240,26 @@ def main():
         note("timed region: %.3f s, %.1f utt/s" % (dt, a.batch * world * a.steps / dt))
         utt = a.batch * world * a.steps / dt
         fpu = flops_per_utt(cfg, a.seq_len, St)
+        if a.model == "bert" and a.seq_len == 128 and a.n_best == 5 and a.batch == 256 and not a.add_l2_loss:
+            cfg_label = "BASELINE configs[1]"
+        elif a.model == "xlm-roberta" and a.seq_len == 128 and a.n_best == 5:
+            cfg_label = "BASELINE configs[2] per-GPU shard (global 256 / DP 8 = 32)" if a.batch == 32 else "BASELINE configs[2] shape"
+        elif a.model == "bert" and a.add_l2_loss and a.seq_len == 256 and a.n_best == 10:
+            cfg_label = "BASELINE configs[3] shape"
+        elif a.model == "xlm-roberta-large" and a.seq_len == 256:
+            cfg_label = "BASELINE configs[4] shape in bf16 (the fp8-weight path is not built)"
+        else:
+            cfg_label = "custom shape"
         res = {
             "metric": "utterances/sec fine-tune (bert-base, seq128, n_best=5)" if a.model == "bert" else "utterances/sec fine-tune (%s)" % a.model,
             "value": round(utt, 2), "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %s shape (random init), %s, synthetic n_best=%d seq_len=%d, batch %d per GPU, "
-                                   "fwd+losses+bwd+allreduce+BertAdam, dropout %s" % (
-                                       {"bert": "bert-base-uncased", "xlm-roberta": "xlm-roberta-base"}.get(a.model, a.model), a.dtype, a.n_best, a.seq_len,
-                                       a.batch, "off" if a.no_dropout else "on (0.1/0.1/0.3)"),
+            "config": {"workload": "%s: %s shape (random init), %s, synthetic n_best=%d seq_len=%d, batch %d per GPU, "
+                                   "fwd+losses+bwd+allreduce+BertAdam%s, dropout %s" % (
+                                       cfg_label, {"bert": "bert-base-uncased", "xlm-roberta": "xlm-roberta-base"}.get(a.model, a.model), a.dtype,
+                                       a.n_best, a.seq_len, a.batch, " + transcript pass and CLS-MSE (--add_l2_loss)" if a.add_l2_loss else "",
+                                       "off" if a.no_dropout else "on (0.1/0.1/0.3)"),
                        "global_batch": a.batch * world, "seq_len": a.seq_len, "n_best": a.n_best, "parallelism": "dp%d" % world,
                        "add_l2_loss": bool(a.add_l2_loss)},
             "flops_per_utterance": fpu,
