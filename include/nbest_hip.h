@@ -78,7 +78,7 @@ enum {
   NBEST_EPI_BIAS = 1,          /* C = acc + bias[n]                                          */
   NBEST_EPI_BIAS_GELU = 2,     /* u = acc + bias[n]; C = gelu_erf(u); U = gelu'(u) (both stored) */
   NBEST_EPI_BIAS_DROP_RES = 3, /* C = drop(acc + bias[n]) + R[m,n]                           */
-  NBEST_EPI_DGELU = 4,         /* C = acc * U[m,n]   (U = gelu'(u) saved by BIAS_GELU)       */
+  NBEST_EPI_DGELU = 4,         /* C = acc * U[m,n]   (U = gelu'(u) saved by BIAS_GELU, see U) */
   NBEST_EPI_RES = 5,           /* C = acc + R[m,n]                                           */
   NBEST_EPI_F32_SPLITK = 6     /* Cf32[N x ...] = sum over K-splits (weight gradient), fp32  */
 };
@@ -88,7 +88,9 @@ typedef struct nbest_gemm_args {
   void* C;            /* dtype output (or fp32 when epilogue == NBEST_EPI_F32_SPLITK)          */
   const float* bias;  /* [N] or NULL                                                          */
   const void* R;      /* residual [M][ldr], dtype                                             */
-  void* U;            /* GELU derivative [M][ldu], dtype: written by BIAS_GELU, read by DGELU */
+  void* U;            /* GELU derivative gelu'(u) [M][ldu]: written by BIAS_GELU, read by DGELU.  NBEST_F32: float.
+                         NBEST_BF16: ONE BYTE per element, fixed point q = round(200 g') + 26 (step 1/200 over
+                         [-0.13, 1.145], 0 and 1 exact), ldu in bytes                                       */
   void* ws;           /* split-K slabs: >= nbest_gemm_ws_bytes(args)                           */
   size_t ws_bytes;
   int64_t M, N, K;

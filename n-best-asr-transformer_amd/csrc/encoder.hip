@@ -7,7 +7,7 @@
 //   X[0..L]   [M][H] T      X[0] = embedding output, X[l+1] = output of layer l
 //   emb_stats [M][2] f32
 //   per layer: qkv [M][3H] T | ctx [M][H] T | lse [B*heads*S] f32 | r1 [M][H] T | st1 [M][2] f32 |
-//              x1 [M][H] T | u = gelu'(pre-activation) [M][F] T | hact [M][F] T | r2 [M][H] T | st2 [M][2] f32
+//              x1 [M][H] T | u = gelu'(pre-activation) [M][F] (fp32, or 8-bit fixed point in the bf16 path) | hact [M][F] T | r2 [M][H] T | st2 [M][2] f32
 // Scratch `ws` (backward): dR | dRd | dB1 | dctx [M][H] T, dBig [M][F] T, dqkv [M][3H] T,
 //              column-reduction partials, split-K slabs, embedding-backward buffer.
 #include "common.h"
@@ -40,7 +40,7 @@ static ActLayout act_layout(const nbest_encoder_desc* d) {
   a.o_r1 = p; p += MH;
   a.o_st1 = p; p += st;
   a.o_x1 = p; p += MH;
-  a.o_u = p; p += MF;
+  a.o_u = p; p += (d->dtype == NBEST_BF16) ? al((size_t)a.M * d->F) : MF;   // GELU': 8 bits per element in the bf16 path
   a.o_hact = p; p += MF;
   a.o_r2 = p; p += MH;
   a.o_st2 = p; p += st;

@@ -120,13 +120,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
   if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
   i32x4 pre[8];
-  if (kHasR || kHasUin) {
-    const bf16* src = kHasR ? p.R : (const bf16*)p.U;
-    const int64_t lds_ = kHasR ? p.ldr : p.ldu;
+  if (kHasR) {              // residual rows: bf16, 16 bytes per lane
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int64_t m = erow0 + it * 8;
-      pre[it] = (m < p.M) ? *(const i32x4*)(src + m * lds_ + en8) : i32x4{0, 0, 0, 0};
+      pre[it] = (m < p.M) ? *(const i32x4*)(p.R + m * p.ldr + en8) : i32x4{0, 0, 0, 0};
+    }
+  }
+  if (kHasUin) {            // GELU' rows: 8-bit (gd_pack4), 8 bytes per lane, kept in .x/.y
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int64_t m = erow0 + it * 8;
+      const i32x2 q = (m < p.M) ? *(const i32x2*)((const uint8_t*)p.U + m * p.ldu + en8) : i32x2{0, 0};
+      pre[it] = i32x4{q[0], q[1], 0, 0};
     }
   }
 
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
         v[e] *= cdf;
       }
-      Vec8<bf16>::store(p.U + m * p.ldu + n8, gp);
+      *(i32x2*)((uint8_t*)p.U + m * p.ldu + n8) = i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)};
     }
     if (EPI == NBEST_EPI_BIAS_DROP_RES) {
       if (p.drop.thr16) {
@@ -253,9 +259,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
       for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
     }
     if (EPI == NBEST_EPI_DGELU) {
-      const bf16x8 u = __builtin_bit_cast(bf16x8, pre[it]);
+      float gd[8];
+      gd_unpack4((uint32_t)pre[it][0], gd);
+      gd_unpack4((uint32_t)pre[it][1], gd + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
+      for (int e = 0; e < 8; ++e) v[e] *= gd[e];
     }
     Vec8<bf16>::store((bf16*)p.C + m * p.ldc + n8, v);
     if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {

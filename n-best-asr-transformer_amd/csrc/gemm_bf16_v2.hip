@@ -151,17 +151,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   constexpr bool kPre = kHasR || kHasUin;
   const int64_t en8 = n0 + wn * WTN + (lane & 7) * 8;
   const int64_t erow0 = m0 + wm * WTM + (lane >> 3);
-  const bf16* esrc = kHasR ? p.R : (const bf16*)p.U;
-  const int64_t eld = kHasR ? p.ldr : p.ldu;
+  // residual rows are bf16 (16 bytes per lane); GELU' rows are 8-bit (gd_pack4: 8 bytes per lane, in .x/.y)
+  auto load_pre = [&](int64_t m) -> i32x4 {
+    if constexpr (kHasR) {
+      return (m < p.M) ? *(const i32x4*)(p.R + m * p.ldr + en8) : i32x4{0, 0, 0, 0};
+    } else {
+      const i32x2 q = (m < p.M) ? *(const i32x2*)((const uint8_t*)p.U + m * p.ldu + en8) : i32x2{0, 0};
+      return i32x4{q[0], q[1], 0, 0};
+    }
+  };
   f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
   if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
   i32x4 pre[TMt / 2][4];   // chunk 0 is fetched before the K loop, the others right after it (fragment registers are dead then)
   if (kPre) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int64_t m = erow0 + it * 8;
-      pre[0][it] = (m < p.M) ? *(const i32x4*)(esrc + m * eld + en8) : i32x4{0, 0, 0, 0};
-    }
+    for (int it = 0; it < 4; ++it) pre[0][it] = load_pre(erow0 + it * 8);
   }
 
   f32x4 acc[TMt][TNt];
@@ -362,10 +366,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
     for (int c = 1; c < TMt / 2; ++c)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int64_t m = erow0 + c * 32 + it * 8;
-        pre[c][it] = (m < p.M) ? *(const i32x4*)(esrc + m * eld + en8) : i32x4{0, 0, 0, 0};
-      }
+      for (int it = 0; it < 4; ++it) pre[c][it] = load_pre(erow0 + c * 32 + it * 8);
   }
   __builtin_amdgcn_s_barrier();   // every wave has finished reading the operand ring
   asm volatile("" ::: "memory");
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
           gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
           v[e] *= cdf;
         }
-        Vec8<bf16>::store(p.U + m * p.ldu + n8, gp);
+        *(i32x2*)((uint8_t*)p.U + m * p.ldu + n8) = i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)};
       }
       if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
         const uint32_t base = (uint32_t)(m * p.N + n8);
@@ -424,9 +425,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
       }
       if (kHasUin) {
-        const bf16x8 u = __builtin_bit_cast(bf16x8, pre[c][it]);
+        float gd[8];
+        gd_unpack4((uint32_t)pre[c][it][0], gd);
+        gd_unpack4((uint32_t)pre[c][it][1], gd + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= (float)u[e];
+        for (int e = 0; e < 8; ++e) v[e] *= gd[e];
       }
       Vec8<bf16>::store((bf16*)p.C + m * p.ldc + n8, v);
       if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
             gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
             v[e] *= cdf;
           }
-          Vec8<bf16>::store(p.U + m * p.ldu + en8, gp);
+          *(i32x2*)((uint8_t*)p.U + m * p.ldu + en8) = i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)};
         }
         Vec8<bf16>::store((bf16*)p.C + m * p.ldc + en8, v);
       }
@@ -802,7 +805,7 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
     NB_CHECK(a->bias, NBEST_ERR_ARG, "gemm: epilogue %d needs bias", epi);
   if (epi == NBEST_EPI_BIAS_DROP_RES || epi == NBEST_EPI_RES)
     NB_CHECK(a->R && a->ldr % 8 == 0 && ((uintptr_t)a->R & 15) == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs R", epi);
-  if (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU)
+  if (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU)   // U: 8-bit GELU' rows (gd_pack4), ldu in bytes
     NB_CHECK(a->U && a->ldu % 8 == 0 && ((uintptr_t)a->U & 15) == 0, NBEST_ERR_ARG, "gemm: epilogue %d needs U", epi);
   if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1)
     NB_CHECK(a->ws && a->ws_bytes >= (size_t)p.splits * a->M * a->N * sizeof(float), NBEST_ERR_WORKSPACE,

@@ -173,8 +173,8 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=No
     dev = A.device
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32_SPLITK else A.dtype, device=dev)
-    if epilogue == EPI_BIAS_GELU and U is None:
-        U = torch.empty(M, N, dtype=A.dtype, device=dev)
+    if epilogue == EPI_BIAS_GELU and U is None:        # gelu'(u): float in the fp32 path, 8-bit fixed point in the bf16 path
+        U = torch.empty(M, N, dtype=torch.float32 if A.dtype == torch.float32 else torch.uint8, device=dev)
     g = GemmArgs()
     g.A, g.B, g.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
     g.bias = bias.data_ptr() if bias is not None else None
@@ -193,6 +193,15 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=No
     g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
     check(lib().nbest_gemm(C.byref(g), stream_ptr()), "gemm")
     return (out, U) if epilogue == EPI_BIAS_GELU else out
+
+
+def gelu_d_decode(U):
+    """gelu'(u) as float from what BIAS_GELU stored (bf16 path: q = round(200 g') + 26 in one byte)"""
+    return U if U.dtype == torch.float32 else (U.float() - 26.0) / 200.0
+
+
+def gelu_d_encode(g):
+    return torch.clamp(torch.floor(g.float() * 200.0 + 26.5), 0, 255).to(torch.uint8)
 
 
 def layernorm_fwd(x, gamma, beta, eps):

@@ -9,7 +9,7 @@ case.  tests/golden/make_golden.py commits that floor per compared quantity; the
 Rounding points (forward; the gradient of each stored tensor is rounded too, as the backward kernels store bf16):
   weight matrices and the three embedding tables (compute copy `w16`; biases / LayerNorm parameters stay fp32),
   X0 = LN(embeddings), per layer qkv, softmax probabilities (MFMA operand of P.V), ctx, r1 = x + dense(ctx),
-  x1 = LN(r1), hact = gelu(u) (and gelu'(u), stored for the backward), r2 = x1 + dense(hact), X = LN(r2).
+  x1 = LN(r1), hact = gelu(u) (gelu'(u), stored for the backward, is 8-bit fixed point), r2 = x1 + dense(hact), X = LN(r2).
 
 TEST INFRASTRUCTURE - see oracle/__init__.py.
 """
@@ -49,14 +49,19 @@ class _RoundWeight(torch.autograd.Function):
         return g
 
 
+def _q8(g):
+    """gelu'(u) as the bf16 path keeps it: 8-bit fixed point, q = round(200 g') + 26 (step 1/200, 0 and 1 exact)"""
+    return (torch.clamp(torch.floor(g * 200.0 + 26.5), 0, 255) - 26.0) / 200.0
+
+
 class _GeluStore(torch.autograd.Function):
-    """FFN-up epilogue: hact = bf16(gelu(u)), stash bf16(gelu'(u)); backward du = bf16(dh * gelu')"""
+    """FFN-up epilogue: hact = bf16(gelu(u)), stash q8(gelu'(u)); backward du = bf16(dh * gelu')"""
 
     @staticmethod
     def forward(ctx, u):
         cdf = 0.5 * (1.0 + torch.erf(u * (1.0 / math.sqrt(2.0))))
         pdf = torch.exp(-0.5 * u * u) * (1.0 / math.sqrt(2.0 * math.pi))
-        ctx.save_for_backward(_r(cdf + u * pdf))
+        ctx.save_for_backward(_q8(cdf + u * pdf))
         return _r(u * cdf)
 
     @staticmethod

@@ -65,15 +65,27 @@ def test_gemm_layouts_and_epilogues(dtype, ta, tb):
     bias = rnd(N, seed=3)
     close(tag + " bias", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_BIAS, bias=bias), ref + bias, tol)
     out, U = hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_BIAS_GELU, bias=bias)
-    close(tag + " bias_gelu.U (= gelu' of the pre-activation)", U, dgelu(ref + bias), tol)
+    # gelu' travels as float in the fp32 path and as 8-bit fixed point (step 1/200, exact 0 and 1) in the bf16 path
+    assert U.dtype == (torch.float32 if dtype == torch.float32 else torch.uint8)
+    if dtype == torch.float32:
+        close(tag + " bias_gelu.U (= gelu' of the pre-activation)", U, dgelu(ref + bias), tol)
+    else:
+        gerr = (hb.gelu_d_decode(U) - dgelu(ref + bias)).abs().max().item()
+        _log("%-58s abs_err=%.3e (quantisation step 5e-3)" % (tag + " bias_gelu.U 8-bit", gerr))
+        assert gerr <= 2.6e-3 + 2e-3, gerr          # half a step + the bf16-input GEMM error on the pre-activation
     close(tag + " bias_gelu.C", out, gelu(ref + bias), tol)
     R = rnd(M, N, dtype=dtype, seed=4)
     close(tag + " bias_res", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_BIAS_DROP_RES, bias=bias, R=R), ref + bias + R.float(), tol)
     close(tag + " res", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_RES, R=R), ref + R.float(), tol)
-    Uin = rnd(M, N, dtype=dtype, seed=5)
+    Uf = dgelu(rnd(M, N, seed=5))                                   # a gelu' field: values in [-0.13, 1.13]
+    Uin = Uf if dtype == torch.float32 else hb.gelu_d_encode(Uf)
+    Ud = hb.gelu_d_decode(Uin)
+    if dtype != torch.float32:
+        assert (Ud - Uf).abs().max().item() <= 2.51e-3
+        assert torch.equal(hb.gelu_d_decode(hb.gelu_d_encode(torch.tensor([0.0, 1.0], device=DEV))), torch.tensor([0.0, 1.0], device=DEV))
     cs = torch.zeros(N, device=DEV)
-    close(tag + " dgelu", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_DGELU, U=Uin, colsum_out=cs), ref * Uin.float(), tol)
-    close(tag + " dgelu fused column sums", cs, (ref * Uin.float()).sum(0), 5 * tol)
+    close(tag + " dgelu", hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_DGELU, U=Uin, colsum_out=cs), ref * Ud, tol)
+    close(tag + " dgelu fused column sums", cs, (ref * Ud).sum(0), 5 * tol)
     got = hb.gemm(A, B, M, N, K, ta, tb, hb.EPI_F32_SPLITK)
     assert got.dtype == torch.float32
     close(tag + " f32_splitk", got, ref, tol)

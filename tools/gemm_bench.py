@@ -54,7 +54,7 @@ def main():
         W = r(N, K)
         bias = torch.randn(N, device=dev)
         out = torch.empty(M, N, dtype=bf, device=dev)
-        U = torch.empty(M, N, dtype=bf, device=dev)
+        U = torch.empty(M, N, dtype=torch.uint8, device=dev)      # gelu' in 8-bit fixed point (bf16 path)
         R = r(M, N)
         fl = 2.0 * M * N * K
         run("fwd  %-9s N=%4d K=%4d none" % (nm, N, K), lambda: hb.gemm(A, W, M, N, K, out=out), fl)
