@@ -235,6 +235,7 @@ def main():
         # below (dominant-kernel timing) must not keep its peers waiting inside a communicator tear-down
         dist.barrier()
         dist.destroy_process_group()
+        reducer = None            # rank 0's in-step kernel timing below runs its extra steps without a gradient exchange
 
     if rank == 0:
         note("timed region: %.3f s, %.1f utt/s" % (dt, a.batch * world * a.steps / dt))
