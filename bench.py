@@ -170,7 +170,8 @@ def main():
     ap.add_argument("--seq_len", type=int, default=128)
     ap.add_argument("--n_best", type=int, default=5)
     ap.add_argument("--model", default="bert", choices=["bert", "xlm-roberta", "xlm-roberta-large"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8w"],
+                    help="fp8w: forward GEMMs on the block-scaled fp8 MFMA from an e4m3 weight copy (reported separately, never the headline)")
     ap.add_argument("--add_l2_loss", action="store_true")
     ap.add_argument("--no_dropout", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
@@ -185,8 +186,9 @@ def main():
     cfg = ncfg.NAMED[a.model]()
     if a.no_dropout:
         cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=dtype, dropout=0.0 if a.no_dropout else 0.3, seed=999)
+    dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
+    model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=dtype, dropout=0.0 if a.no_dropout else 0.3, seed=999,
+                          fp8_forward=(a.dtype == "fp8w"))
     model.load_reference_state(synth.model_state(cfg, labels, seed=999))     # random init of the named architecture
     broadcast_parameters(model)
     model.train()
@@ -267,7 +269,7 @@ def main():
             "step_mfma_frac": round(utt * fpu / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "last_loss_per_utt": round(loss / a.batch, 4),
         }
-        if a.dtype == "bf16" and not a.no_roofline:
+        if a.dtype in ("bf16", "fp8w") and not a.no_roofline:
             ms, fl, by = time_wgrad_in_step(model, step, a.batch, a.seq_len)
             ach = fl / (ms * 1e-3) / 1e12
             traffic, src = wgrad_traffic_from_profiles() if (a.model == "bert" and a.batch == 256 and a.seq_len == 128) else (None, "not measured for this shape")

@@ -114,6 +114,35 @@ size_t nbest_gemm_ws_bytes(const nbest_gemm_args* a);
 int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * fp8 forward GEMMs (dtype path NBEST "fp8w": BASELINE configs[4], "fp8 weights (CDNA4 fp8 MFMA)")
+ * C[M][N] (bf16) = epi((A8[M][K] . W8[N][K]^T) * out_scale + bias): both operands OCP e4m3 (one byte per element, k-contiguous),
+ * on the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; out_scale = 1 / (per-matrix weight scale).
+ * Replaces the same nn.Linear forwards as nbest_gemm (installed modeling_bert.py:154-177, 282-293, 325-351); the
+ * backward stays on the bf16 kernels.  Epilogues: NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU (writes C = gelu bf16, U = gelu' 8-bit,
+ * C8 = e4m3 copy of gelu for the next GEMM), NBEST_EPI_BIAS_DROP_RES.  N % 256 == 0, K % 64 == 0.                      */
+typedef struct nbest_gemm_fp8_args {
+  const void* A;      /* e4m3 [M][lda] */
+  const void* B;      /* e4m3 [N][ldb] (the weight matrix as stored, [out][in]) */
+  void* C;            /* bf16 [M][ldc] */
+  const float* bias;  /* [N] */
+  const void* R;      /* bf16 residual [M][ldr] (BIAS_DROP_RES) */
+  void* U;            /* 8-bit gelu' [M][ldu] (BIAS_GELU), format of nbest_gemm_args::U */
+  void* C8;           /* e4m3 copy of C [M][ldc8] (BIAS_GELU) */
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc, ldr, ldu, ldc8;
+  int32_t epilogue;
+  float out_scale;
+  float drop_p;
+  uint32_t drop_stream;
+  uint64_t seed;
+  const float* out_scale_dev; /* optional DEVICE scalar that overrides out_scale (scales produced on the device by
+                                 nbest_quantize_weights_fp8: no host round trip) */
+} nbest_gemm_fp8_args;
+int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream);
+/* bf16 [n] -> e4m3 [n], unit scale, saturating at +-448 (activations that feed an fp8 GEMM); n % 8 == 0 */
+int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K3  scaled-dot-product attention with a per-sample key-padding mask
  * replaces eager_attention_forward (installed modeling_bert.py:111-136); mask rule of
  * /root/reference/models/model.py:43 is applied by the CALLER (key_mask = ids > 0, uint8 [B,S]).
@@ -230,6 +259,11 @@ typedef struct nbest_matrix_desc {
   int32_t rows, cols;
   int32_t tile_start, pad;
 } nbest_matrix_desc;
+/* e4m3 copy of the weight matrices (same element offsets, ONE byte per element) from the fp32 master, one scale per
+ * matrix: w8 = e4m3(w * 2^floor(log2(224 / max|w|))); inv_scale[i] = 1 / scale of matrix i (device, [n_matrices]).
+ * ws: >= 4 * n_matrices bytes.  Run after every optimizer step, like nbest_transpose_weights.                       */
+int nbest_quantize_weights_fp8(const float* master, void* w8, const nbest_matrix_desc* descs, int n_matrices,
+                               float* inv_scale, void* ws, size_t ws_bytes, nbest_stream_t stream);
 int nbest_transpose_weights(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_tiles,
                             nbest_stream_t stream);
 /* fp32 -> bf16 copy of an arena (initial compute copy / after loading a checkpoint) */
@@ -262,6 +296,12 @@ typedef struct nbest_encoder_desc {
    * launch it enqueues (4 per layer, highest layer first: FFN-down, FFN-up, attention-out, QKV), on the caller's
    * stream, while i < wgrad_events_n / 2.  The library never creates, waits on or destroys events.            */
   void** wgrad_events;
+  /* optional fp8 forward ("fp8w"; dtype must be NBEST_BF16): e4m3 copy of the weight arena (one byte per element at the
+   * same element offsets) and its per-matrix inverse scales [4 L] (QKV, attention-out, FFN-up, FFN-down per layer), both
+   * from nbest_quantize_weights_fp8.  The forward GEMMs then run on the block-scaled fp8 MFMA (activations are cast to
+   * e4m3 with unit scale on the way in); everything else, and the whole backward, is the bf16 path.                      */
+  const void* w8;
+  const float* w8_inv_scale;
 } nbest_encoder_desc;
 size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
 size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);

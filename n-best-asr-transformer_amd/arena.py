@@ -107,6 +107,7 @@ class ParamArena:
         # transposed bf16 copy of the per-layer weight matrices (same offsets): the dgrad GEMMs read it so both of
         # their operands are k-contiguous.  Only allocated on a GPU (the kernel that fills it is HIP).
         self.w16t = None
+        self.w8 = self.w8_inv_scale = self._w8_ws = None
         self._tdescs = None
         if self.w16 is not None and self.device.type == "cuda":
             self.w16t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
@@ -146,10 +147,28 @@ class ParamArena:
         self.refresh_transposed()
 
     def refresh_transposed(self):
+        """the derived copies of the weight matrices the next step reads: k-contiguous bf16 copy for the dgrads and, with
+        the fp8 forward enabled, the e4m3 copy + per-matrix scales (called after every optimizer step)"""
         if self.w16t is not None:
             d, n, t = self._tdescs
             hb.check(hb.lib().nbest_transpose_weights(hb.ptr(self.w16), hb.ptr(self.w16t), hb.ptr(d), n, t, hb.stream_ptr()),
                      "transpose_weights")
+        if self.w8 is not None:
+            d, n, _ = self._tdescs
+            hb.check(hb.lib().nbest_quantize_weights_fp8(hb.ptr(self.p), hb.ptr(self.w8), hb.ptr(d), n, hb.ptr(self.w8_inv_scale),
+                                                         hb.ptr(self._w8_ws), self._w8_ws.numel(), hb.stream_ptr()), "quantize_weights_fp8")
+
+    def enable_fp8_forward(self):
+        """allocate the e4m3 weight copy (one byte per element at the arena's element offsets) and its per-matrix inverse
+        scales [4 L] (QKV, attention-out, FFN-up, FFN-down per layer) - BASELINE configs[4] "fp8 weights"."""
+        if self.w16t is None:
+            raise RuntimeError("nbest_amd: the fp8 forward needs the bf16 path on a GPU")
+        if self.w8 is None:
+            n = self._tdescs[1]
+            self.w8 = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
+            self.w8_inv_scale = torch.ones(n, dtype=torch.float32, device=self.device)
+            self._w8_ws = torch.zeros(4 * n + 16, dtype=torch.uint8, device=self.device)
+            self.refresh_transposed()
 
     def load_state(self, sd, strict=True):
         """copy a reference-keyed state dict (numpy arrays or tensors) into the master arena"""

@@ -50,7 +50,7 @@ static ActLayout act_layout(const nbest_encoder_desc* d) {
 }
 
 struct WsLayout {
-  size_t dR, dRd, dB1, dctx, dBig, dqkv, red, slab, slab_bytes, red_bytes, emb, emb_bytes, total;
+  size_t dR, dRd, dB1, dctx, dBig, dqkv, red, slab, slab_bytes, red_bytes, emb, emb_bytes, f8, f8_bytes, total;
 };
 
 static size_t max_splitk_bytes(const nbest_encoder_desc* d, int64_t M) {
@@ -91,6 +91,9 @@ static WsLayout ws_layout(const nbest_encoder_desc* d) {
   w.slab = o; o += w.slab_bytes;
   w.emb_bytes = al(nbest_embed_bwd_ws_bytes(M, d->H));
   w.emb = o; o += w.emb_bytes;
+  // fp8 forward: e4m3 copies of the GEMM inputs of ONE layer (x | ctx | x1: [M][H] bytes each, gelu(u): [M][F] bytes)
+  w.f8_bytes = (d->dtype == NBEST_BF16) ? 3 * al((size_t)M * d->H) + al((size_t)M * d->F) : 0;
+  w.f8 = o; o += w.f8_bytes;
   w.total = o;
   return w;
 }
@@ -107,6 +110,8 @@ static int check_desc(const nbest_encoder_desc* d) {
   NB_CHECK(d->S <= 512, NBEST_ERR_SHAPE, "encoder: S=%d > 512", d->S);
   if (d->dtype == NBEST_BF16)
     NB_CHECK(d->H % 128 == 0 && d->F % 128 == 0, NBEST_ERR_SHAPE, "encoder(bf16): H and F must be multiples of 128");
+  if (d->w8) NB_CHECK(d->dtype == NBEST_BF16 && d->w8_inv_scale && d->H % 256 == 0 && d->F % 256 == 0, NBEST_ERR_SHAPE,
+                      "encoder(fp8 forward): needs the bf16 path, inverse scales and H, F multiples of 256");
   return NBEST_OK;
 }
 
@@ -149,8 +154,10 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
   NB_CHECK(wts && prm && ids && pos && key_mask && act, NBEST_ERR_ARG, "encoder_forward: null pointer");
   const ActLayout a = act_layout(d);
   NB_CHECK(act_bytes >= a.total, NBEST_ERR_WORKSPACE, "encoder_forward: activation stash too small (%zu < %zu)", act_bytes, a.total);
-  (void)ws; (void)ws_bytes;
   hipStream_t st = (hipStream_t)stream;
+  const bool f8 = d->w8 && d->w8_inv_scale && d->dtype == NBEST_BF16;
+  const WsLayout wl = ws_layout(d);
+  if (f8) NB_CHECK(ws && ws_bytes >= wl.total, NBEST_ERR_WORKSPACE, "encoder_forward(fp8): workspace too small (%zu < %zu)", ws_bytes, wl.total);
   const Ptrs P{(const char*)wts, prm, a.esz};
   char* A = (char*)act;
   const int64_t M = a.M;
@@ -161,6 +168,19 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
 
   RUN(nbest_embed_ln_fwd(ids, seg, pos, P.W(d->off_word), P.W(d->off_type), P.W(d->off_pos), P.P(d->off_emb_ln_g),
                          P.P(d->off_emb_ln_b), X(0), (float*)(A + a.emb_stats), M, H, d->ln_eps, dt, d->hidden_drop, d->seed, sb, st));
+  // fp8 forward: the four GEMMs of a layer on the block-scaled fp8 MFMA; their A operands are e4m3 copies in `ws`
+  uint8_t* x8 = f8 ? (uint8_t*)ws + wl.f8 : nullptr;
+  uint8_t* ctx8 = f8 ? x8 + al((size_t)M * H) : nullptr;
+  uint8_t* x18 = f8 ? ctx8 + al((size_t)M * H) : nullptr;
+  uint8_t* h8 = f8 ? x18 + al((size_t)M * H) : nullptr;
+  auto gemm8 = [&](const uint8_t* A8, int64_t w_off, int mat, void* Cout, int64_t N, int64_t K, int epi, const float* bias, const void* R,
+                   void* U, uint8_t* C8, float drop_p, uint32_t stream_id) -> int {
+    nbest_gemm_fp8_args g = {};
+    g.A = A8; g.B = (const uint8_t*)d->w8 + w_off; g.C = Cout; g.bias = bias; g.R = R; g.U = U; g.C8 = C8;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N; g.ldu = N; g.ldc8 = N;
+    g.epilogue = epi; g.out_scale = 1.f; g.out_scale_dev = d->w8_inv_scale + mat; g.drop_p = drop_p; g.drop_stream = stream_id; g.seed = d->seed;
+    return nbest_gemm_fp8(&g, stream);
+  };
   for (int l = 0; l < d->L; ++l) {
     const nbest_layer_offsets& o = d->layers_host[l];
     char* Lb = A + a.layer0 + (size_t)l * a.layer_stride;
@@ -169,17 +189,32 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     void* u = Lb + a.o_u; void* hact = Lb + a.o_hact; void* r2 = Lb + a.o_r2; float* st2 = (float*)(Lb + a.o_st2);
     const uint32_t s0 = sb + 1 + 4 * l;
     // QKV projection: [M,H] x [3H,H]^T + b
+    if (f8) {
+      RUN(nbest_cast_bf16_to_fp8(X(l), x8, M * H, stream));
+      RUN(gemm8(x8, o.wqkv, 4 * l + 0, qkv, 3 * H, H, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, nullptr, nullptr, 0.f, 0));
+    } else
     RUN(gemm(dt, X(l), P.W(o.wqkv), qkv, M, 3 * H, H, H, H, 3 * H, 0, 0, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, 0, nullptr, 0,
              nullptr, 0, 0, 0.f, 0, 0, st));
     RUN(nbest_attention_fwd(qkv, key_mask, ctx, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream));
     // attention output projection + dropout + residual, then LayerNorm
+    if (f8) {
+      RUN(nbest_cast_bf16_to_fp8(ctx, ctx8, M * H, stream));
+      RUN(gemm8(ctx8, o.wo, 4 * l + 1, r1, H, H, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), nullptr, nullptr, d->hidden_drop, s0 + 1));
+    } else
     RUN(gemm(dt, ctx, P.W(o.wo), r1, M, H, H, H, H, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), H, nullptr, 0, nullptr, 0, 0,
              d->hidden_drop, d->seed, s0 + 1, st));
     RUN(nbest_layernorm_fwd(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, st1, M, H, d->ln_eps, dt, stream));
     // FFN up + bias + GELU (GELU' of the pre-activation kept for the backward)
+    if (f8) {
+      RUN(nbest_cast_bf16_to_fp8(x1, x18, M * H, stream));
+      RUN(gemm8(x18, o.w1, 4 * l + 2, hact, F, H, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, u, h8, 0.f, 0));
+    } else
     RUN(gemm(dt, x1, P.W(o.w1), hact, M, F, H, H, H, F, 0, 0, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, 0, u, F, nullptr, 0, 0, 0.f,
              0, 0, st));
     // FFN down + dropout + residual, then LayerNorm
+    if (f8) {
+      RUN(gemm8(h8, o.w2, 4 * l + 3, r2, H, F, NBEST_EPI_BIAS_DROP_RES, P.P(o.b2), x1, nullptr, nullptr, d->hidden_drop, s0 + 2));
+    } else
     RUN(gemm(dt, hact, P.W(o.w2), r2, M, H, F, F, F, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.b2), x1, H, nullptr, 0, nullptr, 0, 0,
              d->hidden_drop, d->seed, s0 + 2, st));
     RUN(nbest_layernorm_fwd(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), st2, M, H, d->ln_eps, dt, stream));

@@ -1,0 +1,341 @@
+// K2/K4/K6 in fp8: forward GEMMs C = epi((A8 . W8^T) * out_scale) with BOTH operands in OCP e4m3, on the block-scaled
+// matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; the per-tensor weight scale is applied to the
+// fp32 accumulator in the epilogue).  On gfx950 the non-scaled fp8 MFMA runs at the bf16 rate; this one sustains
+// 4.3 PFLOP/s in a register-only loop with random operands against 2.1 for v_mfma_f32_16x16x32_bf16
+// (tools/micro/mx_probe.hip), i.e. twice the math per cycle at half the operand bytes per flop.
+//
+// Structure = the 256x256 ping-pong kernel of gemm_bf16_v2.hip, byte for byte: a stage is 64 k-BYTES (64 fp8 values
+// instead of 32 bf16), so the LDS ring (4 stages x 32 KiB), the LDS-DMA issue count, the counted vmcnt waits and the
+// two-group slot schedule are unchanged; a stage now feeds 8 MFMAs of K = 64 per wave instead of 32 of K = 32.
+//   fragment: lane l holds row (l & 31) of a 32-row block and the 32 bytes [32 g, 32 g + 32) of its 64-byte k-row,
+//             g = l >> 5 (any k order works as long as A and B use the same one - checked by tools/micro/mx_probe.py);
+//   LDS image [rows][64 B]: 16-byte chunk index ^= (row >> 1) & 3 (conflict-free for 8 consecutive rows of one chunk);
+//   C/D: with the operands swapped (B first) lane l owns output row (l & 31) and the columns
+//        (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the 32-column block: four groups of 4 consecutive columns.
+// Epilogues: NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU (writes gelu bf16, gelu' 8-bit AND the fp8 copy of gelu the next GEMM
+// reads), NBEST_EPI_BIAS_DROP_RES.  Outputs are bf16: everything downstream (attention, LayerNorm, backward) is the bf16 path.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+constexpr int BK8 = 64;
+
+struct GemmP8 {
+  const uint8_t* A; const uint8_t* B; bf16* C; const float* bias; const bf16* R; uint8_t* U; uint8_t* C8;
+  int64_t M, N, K, lda, ldb, ldc, ldr, ldu, ldc8;
+  int tiles_m, tiles_n;
+  uint32_t a_bytes, b_bytes;
+  float out_scale;
+  const float* out_scale_dev;
+  DropCfg drop;
+};
+
+__device__ __forceinline__ int xcd_remap8(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// one operand tile: 256 rows x 64 bytes = 1024 16-byte chunks, 512 threads -> 2 LDS-DMA instructions per thread
+__device__ __forceinline__ void stage_tile8(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = i * 512 + tid;
+    const int row = p >> 2, slot = p & 3;
+    const int kc = slot ^ ((row >> 1) & 3);
+    const uint32_t voff = (uint32_t)((row0 + row) * ld + k0 + kc * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * 512 + wave * 64) * 16), 16, voff, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ i32x8 read_frag8(const char* tile, int row_base, int lane) {
+  const int row = row_base + (lane & 31), g = lane >> 5, sw = (row >> 1) & 3;
+  const i32x4 lo = *(const i32x4*)(tile + row * 64 + (((2 * g) ^ sw) << 4));
+  const i32x4 hi = *(const i32x4*)(tile + row * 64 + (((2 * g + 1) ^ sw) << 4));
+  return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int N> __device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ uint32_t fp8_pack4(const float* v) {   // OCP e4m3fn, saturating at +-448
+  float c[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e], -448.f, 448.f);
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+  return (uint32_t)w;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int BM = 256, BN = 256, WN = 4, NT = 512, STAGES = 4;
+  constexpr int WTM = 128, WTN = 64, TMb = 4, TNb = 2;              // 32x32 blocks per wave tile
+  constexpr int A_BYTES = BM * BK8, STAGE = 2 * A_BYTES;            // 16 KiB + 16 KiB
+  constexpr int NDMA = 4;                                           // LDS-DMA instructions per thread and stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int id = xcd_remap8(blockIdx.x, gridDim.x);
+  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+  const int nk = (int)(p.K / BK8);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+
+  constexpr bool kHasR = (EPI == NBEST_EPI_BIAS_DROP_RES);
+  const int64_t en8 = n0 + wn * WTN + (lane & 7) * 8;
+  const int64_t erow0 = m0 + wm * WTM + (lane >> 3);
+  const f32x4 pb0 = *(const f32x4*)(p.bias + en8), pb1 = *(const f32x4*)(p.bias + en8 + 4);
+  const float oscale = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;
+  i32x4 pre[TMb][4];
+  if (kHasR) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t m = erow0 + it * 8;
+      pre[0][it] = (m < p.M) ? *(const i32x4*)(p.R + m * p.ldr + en8) : i32x4{0, 0, 0, 0};
+    }
+  }
+
+  f32x16 acc[TMb][TNb];
+#pragma unroll
+  for (int i = 0; i < TMb; ++i)
+#pragma unroll
+    for (int j = 0; j < TNb; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- ping-pong main loop (see gemm_bf16_v2.hip: the two waves of every SIMD run one slot out of phase) ----
+  const int grp = __builtin_amdgcn_readfirstlane(wm);
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0) {
+    if (s0 < nk) {
+      stage_tile8(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
+      stage_tile8(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
+    }
+  }
+  {
+    const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
+    if (younger >= 2) wait_vm8<2 * NDMA>();
+    else if (younger == 1) wait_vm8<NDMA>();
+    else wait_vm8<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  i32x8 af[TMb], bfr[TNb];
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---------------- LOAD slot ----------------
+    if (kt + STAGES - 1 < nk) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      const int64_t k0 = (int64_t)(kt + STAGES - 1) * BK8;
+      stage_tile8(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+      stage_tile8(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+    }
+    const char* cur = lds + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < TNb; ++j) bfr[j] = read_frag8(cur + A_BYTES, wn * WTN + j * 32, lane);
+#pragma unroll
+    for (int i = 0; i < TMb; ++i) af[i] = read_frag8(cur, wm * WTM + i * 32, lane);
+    {
+      const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1;   // stages kt+1.. outstanding
+      if (c >= 3) wait_vm8<2 * NDMA>();
+      else if (c == 2) wait_vm8<NDMA>();
+      else if (c == 1) wait_vm8<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- MFMA slot ----------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TMb; ++i)
+#pragma unroll
+      for (int j = 0; j < TNb; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 127, 0, 127);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: 32-row blocks restaged through wave-private LDS ([32][64] fp32, chunk16 ^= row & 15) ----
+  float* ep = (float*)lds + wave * 2048;
+  if (kHasR) {
+#pragma unroll
+    for (int c = 1; c < TMb; ++c)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t m = erow0 + c * 32 + it * 8;
+        pre[c][it] = (m < p.M) ? *(const i32x4*)(p.R + m * p.ldr + en8) : i32x4{0, 0, 0, 0};
+      }
+  }
+  __builtin_amdgcn_s_barrier();   // every wave has finished reading the operand ring
+  asm volatile("" ::: "memory");
+  const int hh = lane >> 5, wrow = lane & 31;
+#pragma unroll
+  for (int c = 0; c < TMb; ++c) {
+#pragma unroll
+    for (int j = 0; j < TNb; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cw = 8 * j + 2 * q + hh;   // 16-byte chunk: columns 32 j + 8 q + 4 hh .. + 3
+        *(f32x4*)(ep + wrow * 64 + ((cw ^ (wrow & 15)) << 2)) =
+            f32x4{acc[c][j][4 * q], acc[c][j][4 * q + 1], acc[c][j][4 * q + 2], acc[c][j][4 * q + 3]};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pidx = it * 64 + lane, row = pidx >> 3, c8 = pidx & 7;
+      const int64_t m = m0 + wm * WTM + c * 32 + row;
+      const f32x4 v0 = *(const f32x4*)(ep + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
+      const f32x4 v1 = *(const f32x4*)(ep + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+      if (m >= p.M) continue;
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = fmaf(v[e], oscale, pb0[e]); v[4 + e] = fmaf(v[4 + e], oscale, pb1[e]); }
+      if (EPI == NBEST_EPI_BIAS_GELU) {
+        float gp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float cdf, ex;
+          gelu_parts_fast(v[e], cdf, ex);
+          gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);
+          v[e] *= cdf;
+        }
+        *(i32x2*)(p.U + m * p.ldu + en8) = i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)};
+        *(i32x2*)(p.C8 + m * p.ldc8 + en8) = i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)};
+      }
+      if (EPI == NBEST_EPI_BIAS_DROP_RES) {
+        if (p.drop.thr16) {
+          const uint32_t base = (uint32_t)(m * p.N + en8);
+          const uint32_t k = nb_keep4(p.drop, base) | (nb_keep4(p.drop, base + 4) << 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
+        }
+        const bf16x8 r = __builtin_bit_cast(bf16x8, pre[c][it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+      }
+      Vec8<bf16>::store(p.C + m * p.ldc + en8, v);
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
+// bf16 [n] -> e4m3 (unit scale): the A operands of the fp8 forward GEMMs that no producer kernel writes directly
+__global__ __launch_bounds__(256) void cast_bf16_fp8_kernel(const bf16* __restrict__ src, uint8_t* __restrict__ dst, int64_t n) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 256 * 8) {
+    float v[8];
+    Vec8<bf16>::load(src + i, v);
+    *(i32x2*)(dst + i) = i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)};
+  }
+}
+
+// per-matrix quantisation of the weights: w8 = e4m3(w * scale), scale = 2^floor(log2(224 / max|w|)) (a power of two: exact)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ w, const nbest_matrix_desc* __restrict__ descs,
+                                                     uint32_t* __restrict__ amax_bits) {
+  __shared__ float sm[16];
+  const nbest_matrix_desc d = descs[blockIdx.y];
+  const int64_t n = (int64_t)d.rows * d.cols;
+  float mx = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    const f32x4 x = *(const f32x4*)(w + d.offset + i);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
+  }
+  mx = wave_max(mx);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    atomicMax(amax_bits + blockIdx.y, __float_as_uint(mx));   // non-negative floats order like their bit patterns
+  }
+}
+__global__ __launch_bounds__(256) void quant_w8_kernel(const float* __restrict__ w, uint8_t* __restrict__ w8,
+                                                       const nbest_matrix_desc* __restrict__ descs,
+                                                       const uint32_t* __restrict__ amax_bits, float* __restrict__ inv_scale) {
+  const nbest_matrix_desc d = descs[blockIdx.y];
+  const int64_t n = (int64_t)d.rows * d.cols;
+  const float amax = __uint_as_float(amax_bits[blockIdx.y]);
+  const float scale = (amax > 0.f) ? exp2f(floorf(log2f(224.f / amax))) : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[blockIdx.y] = 1.f / scale;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 2048) {
+    float v[8];
+    Vec8<float>::load(w + d.offset + i, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= scale;
+    *(i32x2*)(w8 + d.offset + i) = i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)};
+  }
+}
+
+}  // namespace
+
+extern "C" int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream) {
+  NB_CHECK(src && dst && n > 0 && n % 8 == 0, NBEST_ERR_ARG, "cast_bf16_to_fp8: bad arguments");
+  int64_t g = (n / 8 + 255) / 256;
+  if (g > 4096) g = 4096;
+  cast_bf16_fp8_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)src, (uint8_t*)dst, n);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_quantize_weights_fp8(const float* master, void* w8, const nbest_matrix_desc* descs, int n_matrices,
+                                          float* inv_scale, void* ws, size_t ws_bytes, nbest_stream_t stream) {
+  NB_CHECK(master && w8 && descs && inv_scale && ws && n_matrices > 0, NBEST_ERR_ARG, "quantize_weights_fp8: bad arguments");
+  NB_CHECK(ws_bytes >= (size_t)n_matrices * sizeof(uint32_t), NBEST_ERR_WORKSPACE, "quantize_weights_fp8: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  NB_CHECK(hipMemsetAsync(ws, 0, (size_t)n_matrices * sizeof(uint32_t), st) == hipSuccess, NBEST_ERR_LAUNCH, "quantize_weights_fp8: memset failed");
+  absmax_kernel<<<dim3(64, n_matrices), 256, 0, st>>>(master, descs, (uint32_t*)ws);
+  NB_LAUNCH_CHECK();
+  quant_w8_kernel<<<dim3(64, n_matrices), 256, 0, st>>>(master, (uint8_t*)w8, descs, (const uint32_t*)ws, inv_scale);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream) {
+  NB_CHECK(a && a->A && a->B && a->C && a->bias, NBEST_ERR_ARG, "gemm_fp8: null pointer");
+  NB_CHECK(a->M > 0 && a->N % 256 == 0 && a->K % BK8 == 0 && a->K >= BK8, NBEST_ERR_SHAPE,
+           "gemm_fp8: needs N %% 256 == 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", (long long)a->M, (long long)a->N, (long long)a->K);
+  NB_CHECK(a->lda % 16 == 0 && a->ldb % 16 == 0 && a->ldc % 8 == 0, NBEST_ERR_ALIGN, "gemm_fp8: leading dimensions");
+  NB_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0, NBEST_ERR_ALIGN,
+           "gemm_fp8: pointers must be 16-byte aligned");
+  const int epi = a->epilogue;
+  NB_CHECK(epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES, NBEST_ERR_ARG,
+           "gemm_fp8: epilogue %d is not built (forward GEMMs only)", epi);
+  if (epi == NBEST_EPI_BIAS_GELU)
+    NB_CHECK(a->U && a->C8 && a->ldu % 8 == 0 && a->ldc8 % 8 == 0 && ((uintptr_t)a->U & 7) == 0 && ((uintptr_t)a->C8 & 7) == 0,
+             NBEST_ERR_ARG, "gemm_fp8: BIAS_GELU needs U (8-bit gelu') and C8 (fp8 copy of the output)");
+  if (epi == NBEST_EPI_BIAS_DROP_RES)
+    NB_CHECK(a->R && a->ldr % 8 == 0 && ((uintptr_t)a->R & 15) == 0, NBEST_ERR_ARG, "gemm_fp8: BIAS_DROP_RES needs R");
+  GemmP8 p;
+  p.A = (const uint8_t*)a->A; p.B = (const uint8_t*)a->B; p.C = (bf16*)a->C; p.bias = a->bias; p.R = (const bf16*)a->R;
+  p.U = (uint8_t*)a->U; p.C8 = (uint8_t*)a->C8;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldu = a->ldu; p.ldc8 = a->ldc8;
+  p.tiles_m = (int)((a->M + 255) / 256);
+  p.tiles_n = (int)(a->N / 256);
+  const int64_t ab = (a->M - 1) * a->lda + a->K, bb = (a->N - 1) * a->ldb + a->K;
+  NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm_fp8: operand larger than 4 GiB");
+  p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  p.out_scale = a->out_scale;
+  p.out_scale_dev = a->out_scale_dev;
+  p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
+  NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm_fp8: dropout counter overflow");
+  const int grid = p.tiles_m * p.tiles_n;
+  constexpr int lds_bytes = 4 * 2 * 256 * BK8;
+  hipStream_t st = (hipStream_t)stream;
+#define L8(E)                                                                                                          \
+  case E:                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)gemm8_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);    \
+    gemm8_kernel<E><<<grid, 512, lds_bytes, st>>>(p);                                                                  \
+    break;
+  switch (epi) { L8(NBEST_EPI_BIAS) L8(NBEST_EPI_BIAS_GELU) L8(NBEST_EPI_BIAS_DROP_RES) default: break; }
+#undef L8
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}

@@ -21,7 +21,7 @@ EXPORTS = [
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
-    "nbest_encoder_backward",
+    "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
 ]
 
 
@@ -33,6 +33,14 @@ class GemmArgs(C.Structure):
                 ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("dtype", C.c_int32),
                 ("accumulate", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64),
                 ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("flags", C.c_int32)]
+
+
+class GemmFp8Args(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p), ("U", C.c_void_p),
+                ("C8", C.c_void_p), ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64), ("ldu", C.c_int64), ("ldc8", C.c_int64),
+                ("epilogue", C.c_int32), ("out_scale", C.c_float), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64),
+                ("out_scale_dev", C.c_void_p)]
 
 
 class LabelSpaceC(C.Structure):
@@ -61,7 +69,8 @@ class EncoderDesc(C.Structure):
                 ("off_word", C.c_int64), ("off_pos", C.c_int64), ("off_type", C.c_int64),
                 ("off_emb_ln_g", C.c_int64), ("off_emb_ln_b", C.c_int64),
                 ("layers_host", C.POINTER(LayerOffsets)), ("seed", C.c_uint64), ("drop_stream_base", C.c_uint32),
-                ("wgrad_events_n", C.c_int32), ("wgrad_events", C.POINTER(C.c_void_p))]
+                ("wgrad_events_n", C.c_int32), ("wgrad_events", C.POINTER(C.c_void_p)),
+                ("w8", C.c_void_p), ("w8_inv_scale", C.c_void_p)]
 
 
 _lib = None
@@ -107,6 +116,9 @@ def lib():
         L.nbest_encoder_forward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 7 + [sz, vp, sz, C.POINTER(C.c_void_p), vp]
         L.nbest_encoder_backward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 9 + [sz, vp, vp, sz, i32, i32, i32, i32, vp]
         L.nbest_transpose_weights.argtypes = [vp, vp, vp, i32, i32, vp]
+        L.nbest_gemm_fp8.argtypes = [C.POINTER(GemmFp8Args), vp]
+        L.nbest_cast_bf16_to_fp8.argtypes = [vp, vp, i64, vp]
+        L.nbest_quantize_weights_fp8.argtypes = [vp, vp, vp, i32, vp, vp, sz, vp]
         L.nbest_last_error.argtypes = [C.c_char_p, sz]
         _lib = L
     return _lib
@@ -202,6 +214,33 @@ def gelu_d_decode(U):
 
 def gelu_d_encode(g):
     return torch.clamp(torch.floor(g.float() * 200.0 + 26.5), 0, 255).to(torch.uint8)
+
+
+def cast_fp8(x):
+    """bf16 -> e4m3 bytes (unit scale, saturating): the A operand of an fp8 forward GEMM"""
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib().nbest_cast_bf16_to_fp8(ptr(x), ptr(out), x.numel(), stream_ptr()), "cast_bf16_to_fp8")
+    return out
+
+
+def gemm_fp8(A8, W8, M, N, K, bias, out_scale=1.0, epilogue=EPI_BIAS, R=None, drop_p=0.0, seed=0, drop_stream=0, out=None):
+    """C[M,N] (bf16) = epi((A8 . W8^T) * out_scale + bias), A8 / W8 e4m3 bytes; BIAS_GELU also returns (U 8-bit gelu', C8 fp8 copy)"""
+    dev = A8.device
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    g = GemmFp8Args()
+    g.A, g.B, g.C, g.bias = A8.data_ptr(), W8.data_ptr(), out.data_ptr(), bias.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, A8.stride(0), W8.stride(0), out.stride(0)
+    g.epilogue, g.out_scale, g.drop_p, g.drop_stream, g.seed = epilogue, out_scale, drop_p, drop_stream, seed
+    U = C8 = None
+    if epilogue == EPI_BIAS_GELU:
+        U = torch.empty(M, N, dtype=torch.uint8, device=dev)
+        C8 = torch.empty(M, N, dtype=torch.uint8, device=dev)
+        g.U, g.C8, g.ldu, g.ldc8 = U.data_ptr(), C8.data_ptr(), N, N
+    if R is not None:
+        g.R, g.ldr = R.data_ptr(), R.stride(0)
+    check(lib().nbest_gemm_fp8(C.byref(g), stream_ptr()), "gemm_fp8")
+    return (out, U, C8) if epilogue == EPI_BIAS_GELU else out
 
 
 def layernorm_fwd(x, gamma, beta, eps):

@@ -76,12 +76,19 @@ class _Pass:
 
 class NBestSTCModel(nn.Module):
     def __init__(self, cfg: EncoderConfig, labels: LabelSpace, device="cuda", compute_dtype=torch.bfloat16, dropout=0.0,
-                 seed=999):
+                 seed=999, fp8_forward=False):
         super().__init__()
         self.cfg, self.labels, self.compute_dtype = cfg, labels, compute_dtype
         self.dropout = float(dropout)                  # --dropout: feature dropout of the STC heads
         self.device = torch.device(device)
         self.arena = ParamArena(cfg, labels, self.device, compute_dtype)
+        # "fp8w" (BASELINE configs[4]): forward GEMMs on the block-scaled fp8 MFMA from an e4m3 copy of the weights; the
+        # master weights, the backward and everything between the GEMMs stay as in the bf16 path
+        self.fp8_forward = bool(fp8_forward)
+        if self.fp8_forward:
+            if compute_dtype != torch.bfloat16:
+                raise RuntimeError("nbest_amd: fp8_forward rides on the bf16 path")
+            self.arena.enable_fp8_forward()
         self.bert_encoder = _Holder()
         self.clf = _Holder()
         for s in self.arena.slots:
@@ -191,6 +198,8 @@ class NBestSTCModel(nn.Module):
         d.hidden_drop = cfg.hidden_dropout_prob if train else 0.0
         d.attn_drop = cfg.attention_probs_dropout_prob if train else 0.0
         d.seed = self._step_seed()
+        if self.fp8_forward:
+            d.w8, d.w8_inv_scale = self.arena.w8.data_ptr(), self.arena.w8_inv_scale.data_ptr()
         out = C.c_void_p()
         hb.check(hb.lib().nbest_encoder_forward(C.byref(d), hb.ptr(self.arena.weights), hb.ptr(self.arena.p), hb.ptr(ids),
                                                 hb.ptr(seg), hb.ptr(pos), hb.ptr(mask), hb.ptr(ps.act), ps.act.numel(),
@@ -304,4 +313,4 @@ def make_model(opt):
     labels = LabelSpace(opt.top2bottom_dict, list(getattr(opt, "idx2label", []) or []))
     return NBestSTCModel(cfg, labels, device=getattr(opt, "device", "cuda"),
                          compute_dtype=getattr(opt, "compute_dtype", torch.bfloat16), dropout=getattr(opt, "dropout", 0.0),
-                         seed=getattr(opt, "random_seed", 999))
+                         seed=getattr(opt, "random_seed", 999), fp8_forward=getattr(opt, "fp8_forward", False))

@@ -96,6 +96,44 @@ class _AttnCore(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
+def _e4m3(x):
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+class _Fp8Linear(torch.autograd.Function):
+    """"fp8w" forward GEMM: y = e4m3(x) . e4m3(W * s)^T / s + b with the per-matrix power-of-two scale
+    s = 2^floor(log2(224 / max|W|)) (nbest_quantize_weights_fp8) and unit-scale activations (nbest_cast_bf16_to_fp8); the
+    backward is the bf16 path's (dgrad on the bf16 weight copy, weight gradient from the bf16 activation)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        s = 2.0 ** torch.floor(torch.log2(224.0 / w.abs().max()))
+        ctx.save_for_backward(x, _r(w))
+        return F.linear(_e4m3(x), _e4m3(w * s)) / s + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w16 = ctx.saved_tensors
+        return g @ w16, (g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])), g.reshape(-1, g.shape[-1]).sum(0)
+
+
+class _GeluStoreFp8(torch.autograd.Function):
+    """as _GeluStore; the fp8 forward's next GEMM reads the e4m3 copy of gelu(u) written by the same epilogue (from the
+    fp32 value), so the rounding to bf16 is on the stored tensor only"""
+
+    @staticmethod
+    def forward(ctx, u):
+        cdf = 0.5 * (1.0 + torch.erf(u * (1.0 / math.sqrt(2.0))))
+        pdf = torch.exp(-0.5 * u * u) * (1.0 / math.sqrt(2.0 * math.pi))
+        ctx.save_for_backward(_q8(cdf + u * pdf))
+        return u * cdf
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return _r(g * d)
+
+
 ract, rw = _RoundAct.apply, _RoundWeight.apply
 
 
@@ -103,8 +141,9 @@ def _ln(x, mod):
     return F.layer_norm(x, (x.shape[-1],), mod.weight, mod.bias, mod.eps)
 
 
-def encode(enc, ids, seg):
-    """oracle.encoder.OracleEncoder.forward with bf16 storage (dropout must be off: parity runs use p = 0)"""
+def encode(enc, ids, seg, fp8=False):
+    """oracle.encoder.OracleEncoder.forward with bf16 storage (dropout must be off: parity runs use p = 0); ``fp8``: the
+    four forward GEMMs of every layer as the "fp8w" path runs them (e4m3 operands, see _Fp8Linear)"""
     cfg = enc.cfg
     key_mask = ids > 0                                                     # quirk Q1 (models/model.py:43)
     if seg is None:
@@ -119,31 +158,51 @@ def encode(enc, ids, seg):
     B, S, H = x.shape
     nh = cfg.num_attention_heads
     d = H // nh
+    lin = (lambda inp, m: _Fp8Linear.apply(inp, m.weight, m.bias)) if fp8 else (lambda inp, m: F.linear(inp, rw(m.weight), m.bias))
     for lyr in enc.encoder.layer:
         a = lyr.attention.self
         split = lambda t: t.view(B, S, nh, d).transpose(1, 2)
-        q = ract(F.linear(x, rw(a.query.weight), a.query.bias))
-        k = ract(F.linear(x, rw(a.key.weight), a.key.bias))
-        v = ract(F.linear(x, rw(a.value.weight), a.value.bias))
+        q, k, v = ract(lin(x, a.query)), ract(lin(x, a.key)), ract(lin(x, a.value))
         o = _AttnCore.apply(split(q), split(k), split(v), key_mask, 1.0 / math.sqrt(d))
         ctx = ract(o.transpose(1, 2).reshape(B, S, H))
         ao = lyr.attention.output
-        r1 = ract(F.linear(ctx, rw(ao.dense.weight), ao.dense.bias) + x)
+        r1 = ract(lin(ctx, ao.dense) + x)
         x1 = ract(_ln(r1, ao.LayerNorm))
-        hact = _GeluStore.apply(F.linear(x1, rw(lyr.intermediate.dense.weight), lyr.intermediate.dense.bias))
-        r2 = ract(F.linear(hact, rw(lyr.output.dense.weight), lyr.output.dense.bias) + x1)
+        if fp8:
+            # gelu(u) reaches the next GEMM as e4m3 of the fp32 value; the bf16 copy feeds the backward (weight gradient)
+            h32 = _GeluStoreFp8.apply(lin(x1, lyr.intermediate.dense))
+            r2 = ract(_Fp8LinearPre.apply(h32, lyr.output.dense.weight, lyr.output.dense.bias) + x1)
+        else:
+            hact = _GeluStore.apply(lin(x1, lyr.intermediate.dense))
+            r2 = ract(lin(hact, lyr.output.dense) + x1)
         x = ract(_ln(r2, lyr.output.LayerNorm))
     return x[:, 0, :]
 
 
-def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None):
+class _Fp8LinearPre(torch.autograd.Function):
+    """_Fp8Linear whose input arrives in fp32 (gelu(u) straight from the epilogue): forward on e4m3(input), backward on its
+    bf16 copy, gradient to the input rounded to bf16 (the stored dU path)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        s = 2.0 ** torch.floor(torch.log2(224.0 / w.abs().max()))
+        ctx.save_for_backward(_r(x), _r(w))
+        return F.linear(_e4m3(x), _e4m3(w * s)) / s + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x16, w16 = ctx.saved_tensors
+        return _r(g @ w16), (g.reshape(-1, g.shape[-1]).t() @ x16.reshape(-1, x16.shape[-1])), g.reshape(-1, g.shape[-1]).sum(0)
+
+
+def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, fp8=False):
     """oracle.model.OracleModel.forward (classifier_input_type 'asr') on the bf16-storage encoder; heads in fp32"""
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             assert m.p == 0.0 or not model.training
     if model.family == "xlm-roberta":
         seg_ids = trans_seg_ids = None
-    asr_cls = encode(model.bert_encoder, input_ids, seg_ids)
-    trans_cls = encode(model.bert_encoder, trans_input_ids, trans_seg_ids) if trans_input_ids is not None else None
+    asr_cls = encode(model.bert_encoder, input_ids, seg_ids, fp8)
+    trans_cls = encode(model.bert_encoder, trans_input_ids, trans_seg_ids, fp8) if trans_input_ids is not None else None
     top, bottoms, final = model.clf(asr_cls)
     return top, bottoms, final, asr_cls, trans_cls

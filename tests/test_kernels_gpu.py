@@ -380,3 +380,34 @@ def test_cls_mse():
     close("mse loss", loss, ref.detach().reshape(1), 1e-5)
     close("mse da", da, ar.grad, 1e-5)
     close("mse dt", dt, tr.grad, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+def _e4m3(x):
+    return x.to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 192), (424, 768, 768), (300, 3072, 1024), (256, 768, 3072)])
+def test_gemm_fp8_forward_epilogues(M, N, K):
+    """fp8 forward GEMM (block-scaled MFMA, e4m3 x e4m3, unit block scales): with both operands already e4m3 every product is
+    exact in fp32, so the result must match the fp32 matmul of the DEQUANTISED operands to fp32-accumulation accuracy
+    (then bf16 output rounding) - this isolates the kernel from the quantisation."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A8 = _e4m3(torch.randn(M, K, generator=g)).to(DEV)
+    W = torch.randn(N, K, generator=g) * 0.03
+    s = 2.0 ** math.floor(math.log2(224.0 / W.abs().max().item()))
+    W8 = _e4m3(W * s).to(DEV)
+    bias = rnd(N, seed=3)
+    ref = (A8.float() @ W8.float().t()) / s + bias
+    tag = "gemm_fp8[%dx%dx%d]" % (M, N, K)
+    close(tag + " bias", hb.gemm_fp8(A8.view(torch.uint8), W8.view(torch.uint8), M, N, K, bias, 1.0 / s), ref, 1e-2)
+    out, U, C8 = hb.gemm_fp8(A8.view(torch.uint8), W8.view(torch.uint8), M, N, K, bias, 1.0 / s, epilogue=hb.EPI_BIAS_GELU)
+    close(tag + " bias_gelu.C", out, gelu(ref), 1e-2)
+    assert (hb.gelu_d_decode(U) - dgelu(ref)).abs().max().item() <= 2.6e-3 + 1e-3
+    c8 = C8.view(torch.float8_e4m3fn).float()
+    assert torch.equal(c8, _e4m3(out.float().cpu().clamp(-448, 448)).float().to(DEV)) or (c8 - gelu(ref)).abs().max().item() <= 0.07 * gelu(ref).abs().max().item()
+    R = rnd(M, N, dtype=torch.bfloat16, seed=4)
+    close(tag + " bias_res", hb.gemm_fp8(A8.view(torch.uint8), W8.view(torch.uint8), M, N, K, bias, 1.0 / s, epilogue=hb.EPI_BIAS_DROP_RES, R=R),
+          ref + R.float(), 1e-2)
+    x = rnd(M, K, dtype=torch.bfloat16, seed=9)
+    assert torch.equal(hb.cast_fp8(x).view(torch.float8_e4m3fn).float(), _e4m3(x.float().cpu()).float().to(DEV))     # RNE, like torch

@@ -244,7 +244,7 @@ def test_xlmr_large_shape_matches_oracle(dtype, labels):
     _check_vs_oracle(cfg, 3, 72, 24, dtype, labels)
 
 
-def _check_vs_oracle(cfg, B, S, St, dtype, labels):
+def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False):
     from nbest_amd import synth
     from nbest_amd.model import NBestSTCModel
     from oracle import bf16sim, stc
@@ -265,7 +265,7 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels):
         # noise floor of THIS case: the same oracle with bf16 storage (oracle/bf16sim.py) against its fp32 self
         for p in om.parameters():
             p.grad = None
-        stop, sbot, sfin, sasr, str_ = bf16sim.forward(om, t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"])
+        stop, sbot, sfin, sasr, str_ = bf16sim.forward(om, t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"], fp8=fp8)
         _, stotal, _ = stc.total_loss(stop, sbot, sfin, t["labels"], labels.top2bottom, b2t, sasr, str_, True)
         stotal.backward()
         fl_top, fl_fin = (stop - top).abs().max().item(), (sfin - final).abs().max().item()
@@ -273,12 +273,12 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels):
         for n, p in om.named_parameters():
             if n in ref_g:
                 sim_ns[n] = ((p.grad - ref_g[n]).norm() / ref_g[n].norm().clamp_min(1e-30)).item()
-    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0, fp8_forward=fp8)
     m.load_reference_state(sd)
     m.train()
     b = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
     out = m.forward_backward(b["ids"], b["labels"], seg_ids=b["seg"], trans_input_ids=b["tids"], trans_seg_ids=b["tseg"], add_l2_loss=True)
-    tag = "edge %s B=%d S=%d %s " % (cfg.family, B, S, "f32" if f32 else "bf16")
+    tag = "edge %s B=%d S=%d %s " % (cfg.family, B, S, "f32" if f32 else ("fp8w" if fp8 else "bf16"))
     if f32:
         _cmp(tag + "top", out["top"], top.detach(), atol=1e-4)
         _cmp(tag + "final", out["final"], final.detach(), atol=1e-4)
@@ -308,6 +308,21 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels):
     if f32:
         dec = stc.decode_indices(top.detach(), {k: v.detach() for k, v in bottoms.items()}, labels.top2bottom, labels.idx2label)
         assert torch.equal(m.decode(out["top"], out["bott"]).cpu().long(), dec)
+
+
+@pytest.mark.parametrize("family,B,S,St", [("bert", 3, 40, 12), ("bert", 2, 200, 40), ("xlmr-large", 2, 72, 24)])
+def test_fp8_forward_matches_its_oracle_leg(family, B, S, St, labels):
+    """"fp8w" (BASELINE configs[4]: fp8 weights on the CDNA4 fp8 MFMA): forward GEMMs on v_mfma_scale_f32_32x32x64_f8f6f4 from a
+    per-matrix-scaled e4m3 copy of the weights, activations cast to e4m3 on the way in; backward = the bf16 path.  Bar: the
+    same as for bf16 - within 1.5 x the noise floor of the oracle leg that rounds exactly the same tensors
+    (oracle/bf16sim.py, fp8=True), scores, loss and per-tensor gradient noise-to-signal."""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg
+    if family == "bert":
+        cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    else:
+        cfg = ncfg.xlmr_large(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    _check_vs_oracle(cfg, B, S, St, torch.bfloat16, labels, fp8=True)
 
 
 def test_too_long_sequence_fails_loudly(labels):

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""fp8 (block-scaled MFMA) forward GEMMs next to the bf16 kernels on the layer shapes: python tools/gemm_fp8_bench.py [--M 32768 --H 768 --F 3072]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import nbest_amd  # noqa
+from nbest_amd import hipabi as hb
+from gemm_bench import timeit
+ap = argparse.ArgumentParser()
+ap.add_argument("--M", type=int, default=32768); ap.add_argument("--H", type=int, default=768); ap.add_argument("--F", type=int, default=3072)
+a = ap.parse_args()
+M, H, F = a.M, a.H, a.F
+dev = "cuda"
+r = lambda *s: (torch.randn(*s, device=dev) * 0.5)
+for nm, N, K, epi in (("qkv", 3 * H, H, hb.EPI_BIAS), ("attn_out", H, H, hb.EPI_BIAS_DROP_RES), ("ffn_up", F, H, hb.EPI_BIAS_GELU), ("ffn_down", H, F, hb.EPI_BIAS_DROP_RES)):
+    A, W = r(M, K).bfloat16(), r(N, K).bfloat16()
+    A8, W8 = A.float().to(torch.float8_e4m3fn).view(torch.uint8), W.float().to(torch.float8_e4m3fn).view(torch.uint8)
+    bias = torch.randn(N, device=dev)
+    R = r(M, N).bfloat16()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    U = torch.empty(M, N, dtype=torch.uint8, device=dev)
+    fl = 2.0 * M * N * K
+    kw = dict(R=R, drop_p=0.1, seed=1) if epi == hb.EPI_BIAS_DROP_RES else {}
+    t16 = timeit(lambda: hb.gemm(A, W, M, N, K, epilogue=epi, bias=bias, out=out, U=U if epi == hb.EPI_BIAS_GELU else None, **kw))
+    t8 = timeit(lambda: hb.gemm_fp8(A8, W8, M, N, K, bias, 1.0, epilogue=epi, out=out, **kw))
+    print("%-9s N=%4d K=%4d epi %d   bf16 %7.1f us %6.0f TF/s | fp8 %7.1f us %6.0f TF/s  (x%.2f)" % (nm, N, K, epi, t16 * 1e3, fl / t16 / 1e9, t8 * 1e3, fl / t8 / 1e9, t16 / t8), flush=True)
