@@ -87,7 +87,10 @@ def parse_arguments(argv=None):
     g.add_argument("--without_system_act", action="store_true")
     g.add_argument("--add_segment_ids", action="store_true")
     g = ap.add_argument_group("additive flags of this build")
-    g.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    g.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8w"],
+                   help="bf16 (default) | f32 (parity path) | fp8w: the bf16 path with the forward GEMMs on the CDNA4 block-scaled fp8 "
+                        "MFMA from a per-matrix-scaled e4m3 copy of the weights (BASELINE configs[4]: 'fp8 weights'); master weights, "
+                        "backward and optimizer are unchanged")
     g.add_argument("--n_best", type=int, default=None, help="keep only the first n hypotheses of every utterance")
     g.add_argument("--init_checkpoint", default=None, help="state dict (reference keys) to start from")
     g.add_argument("--pretrained_path", default=None,
@@ -186,8 +189,8 @@ def main(argv=None):
         cfg.num_hidden_layers = opt.encoder_layers
     if (family == "bert" and not (opt.init_checkpoint or opt.pretrained_path)) or opt.vocab:
         cfg.vocab_size = max(opt.tokenizer.vocab_size, 8)          # embedding table sized for the local vocabulary
-    model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=torch.bfloat16 if opt.dtype == "bf16" else torch.float32,
-                          dropout=opt.dropout, seed=opt.random_seed)
+    model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=torch.float32 if opt.dtype == "f32" else torch.bfloat16,
+                          dropout=opt.dropout, seed=opt.random_seed, fp8_forward=(opt.dtype == "fp8w"))
     if opt.init_checkpoint:
         model.load_model(opt.init_checkpoint)
     else:

@@ -175,7 +175,7 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
 // write a wave's [32][64] fp32 accumulator pair (columns 0-31 / 32-63; lane = column) into rows
 // row0.. of a plain [rows][64] bf16 LDS image, then store those 32 rows with 16-byte accesses.
 __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0, const f32x16& o1, int lane, bf16* gbase,
-                                           int64_t gld, int rows_valid) {
+                                           int64_t gld, int rows_valid, uint8_t* g8 = nullptr) {   // g8: optional e4m3 copy
   const int hh = lane >> 5, c = lane & 31;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -187,14 +187,24 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = i * 64 + lane, row = p >> 3, ch = p & 7;
-    if (row < rows_valid) *(i32x4*)(gbase + (int64_t)row * gld + ch * 8) = *(const i32x4*)(img + (row0 + row) * 128 + ch * 16);
+    if (row < rows_valid) {
+      const i32x4 v = *(const i32x4*)(img + (row0 + row) * 128 + ch * 16);
+      *(i32x4*)(gbase + (int64_t)row * gld + ch * 8) = v;
+      if (g8) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)b[e];
+        *(i32x2*)(g8 + (int64_t)row * gld + ch * 8) = i32x2{(int)fp8_pack4(f), (int)fp8_pack4(f + 4)};
+      }
+    }
   }
 }
 
 template <int NKB>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                             bf16* __restrict__ ctx, float* __restrict__ lse, int S, int heads,
-                                                            int H, float scale, DropCfg drop) {
+                                                            int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int Sp = NKB * 32;
   char* Kt = lds;
@@ -294,7 +304,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 0, lane), o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 32, lane), o1, 0, 0, 0);
       }
-    store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0);
+    store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0,
+               ctx8 ? ctx8 + ((int64_t)b * S + q0) * H + h * 64 : nullptr);
   }
 }
 
@@ -645,7 +656,7 @@ __device__ __forceinline__ void stage_rows_off(__amdgpu_buffer_rsrc_t rs, char* 
 
 __global__ __launch_bounds__(256) void attn_fwd_long_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                                  bf16* __restrict__ ctx, float* __restrict__ lse, int S, int nkb,
-                                                                 int heads, int H, float scale, DropCfg drop) {
+                                                                 int heads, int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int Sp = nkb * 32;
   char* Kt = lds;
@@ -744,7 +755,8 @@ __global__ __launch_bounds__(256) void attn_fwd_long_bf16_kernel(const bf16* __r
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 32, lane), o1, 0, 0, 0);
       }
     }
-    store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0);
+    store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0,
+               ctx8 ? ctx8 + ((int64_t)b * S + q0) * H + h * 64 : nullptr);
   }
 }
 
@@ -945,10 +957,10 @@ static size_t bwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * (4 * 128 + 256)
 
 template <int NKB>
 static void launch_fwd(const bf16* qkv, const uint8_t* mask, bf16* ctx, float* lse, int B, int S, int heads, int H, float scale,
-                       DropCfg d, hipStream_t st) {
+                       DropCfg d, hipStream_t st, uint8_t* ctx8) {
   const size_t sm = fwd_lds_bytes(NKB);
   (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  attn_fwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d);
+  attn_fwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8);
 }
 #ifdef NBEST_EXPERIMENTS
 template <int NKB>
@@ -970,8 +982,9 @@ static int check_common(const char* who, int B, int S, int heads, int d, int dty
 
 }  // namespace
 
-extern "C" int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
-                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
+// ctx8 != NULL (bf16 only): also write the e4m3 copy of ctx that the fp8 attention-output GEMM reads
+int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void* ctx, void* ctx8, float* lse, int B, int S, int heads,
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
   NB_CHECK(qkv && key_mask && ctx && lse, NBEST_ERR_ARG, "attention_fwd: null pointer");
   if (int e = check_common("attention_fwd", B, S, heads, d, dtype)) return e;
   hipStream_t st = (hipStream_t)stream;
@@ -988,16 +1001,21 @@ extern "C" int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, voi
     if (nkb > 8) {
       const size_t sm = fwd_lds_bytes(nkb);
       (void)hipFuncSetAttribute((const void*)attn_fwd_long_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-      attn_fwd_long_bf16_kernel<<<B * heads, 256, sm, st>>>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, S, nkb, heads, H, scale, dc);
+      attn_fwd_long_bf16_kernel<<<B * heads, 256, sm, st>>>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, S, nkb, heads, H, scale, dc, (uint8_t*)ctx8);
       NB_LAUNCH_CHECK();
       return NBEST_OK;
     }
-#define F(N) case N: launch_fwd<N>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, S, heads, H, scale, dc, st); break;
+#define F(N) case N: launch_fwd<N>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, S, heads, H, scale, dc, st, (uint8_t*)ctx8); break;
     switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
 #undef F
   }
   NB_LAUNCH_CHECK();
   return NBEST_OK;
+}
+
+extern "C" int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
+                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
+  return nbest_internal_attention_fwd8(qkv, key_mask, ctx, nullptr, lse, B, S, heads, d, dtype, drop_p, seed, drop_stream, stream);
 }
 
 int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);

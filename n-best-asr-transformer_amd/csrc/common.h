@@ -190,6 +190,17 @@ __device__ __forceinline__ void gd_unpack4(uint32_t w, float* g) {
   for (int e = 0; e < 4; ++e) g[e] = fmaf((float)((w >> (8 * e)) & 255u), 0.005f, -0.13f);
 }
 
+// four floats -> four OCP e4m3 bytes (unit scale, saturating at +-448): operands of the fp8 forward GEMMs
+__device__ __forceinline__ uint32_t fp8_pack4(const float* v) {
+  float c[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e], -448.f, 448.f);
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+  return (uint32_t)w;
+}
+
 // ---- counter-based dropout ---------------------------------------------------------------------
 // keep-decision for element `idx` of stream `stream` under (seed): 16-bit uniform compared with a
 // 16-bit threshold.  thr16 = round(p * 65536); the effective drop probability is thr16/65536 and

@@ -12,6 +12,11 @@
 //              column-reduction partials, split-K slabs, embedding-backward buffer.
 #include "common.h"
 
+int nbest_internal_layernorm_fwd8(const void* x, const float* gamma, const float* beta, void* y, void* y8, float* stats,
+                                  int64_t M, int H, float eps, int dtype, nbest_stream_t stream);
+int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void* ctx, void* ctx8, float* lse, int B, int S, int heads,
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream);
+
 namespace {
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -110,7 +115,7 @@ static int check_desc(const nbest_encoder_desc* d) {
   NB_CHECK(d->S <= 512, NBEST_ERR_SHAPE, "encoder: S=%d > 512", d->S);
   if (d->dtype == NBEST_BF16)
     NB_CHECK(d->H % 128 == 0 && d->F % 128 == 0, NBEST_ERR_SHAPE, "encoder(bf16): H and F must be multiples of 128");
-  if (d->w8) NB_CHECK(d->dtype == NBEST_BF16 && d->w8_inv_scale && d->H % 256 == 0 && d->F % 256 == 0, NBEST_ERR_SHAPE,
+  if (d->w8) NB_CHECK(d->dtype == NBEST_BF16 && d->w8_inv_scale && d->H % 256 == 0 && d->H <= 1024 && d->F % 256 == 0, NBEST_ERR_SHAPE,
                       "encoder(fp8 forward): needs the bf16 path, inverse scales and H, F multiples of 256");
   return NBEST_OK;
 }
@@ -190,23 +195,21 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     const uint32_t s0 = sb + 1 + 4 * l;
     // QKV projection: [M,H] x [3H,H]^T + b
     if (f8) {
-      RUN(nbest_cast_bf16_to_fp8(X(l), x8, M * H, stream));
+      if (l == 0) RUN(nbest_cast_bf16_to_fp8(X(0), x8, M * H, stream));   // later layers: written by the previous layer's LayerNorm
       RUN(gemm8(x8, o.wqkv, 4 * l + 0, qkv, 3 * H, H, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, nullptr, nullptr, 0.f, 0));
     } else
     RUN(gemm(dt, X(l), P.W(o.wqkv), qkv, M, 3 * H, H, H, H, 3 * H, 0, 0, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, 0, nullptr, 0,
              nullptr, 0, 0, 0.f, 0, 0, st));
-    RUN(nbest_attention_fwd(qkv, key_mask, ctx, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream));
+    RUN(nbest_internal_attention_fwd8(qkv, key_mask, ctx, ctx8, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream));
     // attention output projection + dropout + residual, then LayerNorm
     if (f8) {
-      RUN(nbest_cast_bf16_to_fp8(ctx, ctx8, M * H, stream));
       RUN(gemm8(ctx8, o.wo, 4 * l + 1, r1, H, H, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), nullptr, nullptr, d->hidden_drop, s0 + 1));
     } else
     RUN(gemm(dt, ctx, P.W(o.wo), r1, M, H, H, H, H, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), H, nullptr, 0, nullptr, 0, 0,
              d->hidden_drop, d->seed, s0 + 1, st));
-    RUN(nbest_layernorm_fwd(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, st1, M, H, d->ln_eps, dt, stream));
+    RUN(nbest_internal_layernorm_fwd8(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, x18, st1, M, H, d->ln_eps, dt, stream));
     // FFN up + bias + GELU (GELU' of the pre-activation kept for the backward)
     if (f8) {
-      RUN(nbest_cast_bf16_to_fp8(x1, x18, M * H, stream));
       RUN(gemm8(x18, o.w1, 4 * l + 2, hact, F, H, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, u, h8, 0.f, 0));
     } else
     RUN(gemm(dt, x1, P.W(o.w1), hact, M, F, H, H, H, F, 0, 0, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, 0, u, F, nullptr, 0, 0, 0.f,
@@ -217,7 +220,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     } else
     RUN(gemm(dt, hact, P.W(o.w2), r2, M, H, F, F, F, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.b2), x1, H, nullptr, 0, nullptr, 0, 0,
              d->hidden_drop, d->seed, s0 + 2, st));
-    RUN(nbest_layernorm_fwd(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), st2, M, H, d->ln_eps, dt, stream));
+    RUN(nbest_internal_layernorm_fwd8(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), x8, st2, M, H, d->ln_eps, dt, stream));
   }
   if (hidden_out) *hidden_out = X(d->L);
   return NBEST_OK;

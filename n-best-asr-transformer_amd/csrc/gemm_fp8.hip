@@ -58,16 +58,6 @@ __device__ __forceinline__ i32x8 read_frag8(const char* tile, int row_base, int 
 
 template <int N> __device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ uint32_t fp8_pack4(const float* v) {   // OCP e4m3fn, saturating at +-448
-  float c[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e], -448.f, 448.f);
-  int w = 0;
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], w, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
-  return (uint32_t)w;
-}
-
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];

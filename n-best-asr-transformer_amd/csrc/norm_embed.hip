@@ -72,7 +72,8 @@ __device__ __forceinline__ uint32_t pack2(f32x2 v) {
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, bf16* __restrict__ y,
-                                                          float* __restrict__ stats, int64_t M, float eps) {
+                                                          float* __restrict__ stats, int64_t M, float eps,
+                                                          uint8_t* __restrict__ y8) {   // optional e4m3 copy of y (fp8 forward)
   constexpr int H = VPL * 256;
   constexpr float invH = 1.0f / (float)H;
   const int lane = threadIdx.x & 63;
@@ -114,7 +115,13 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const bf16* __restrict
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const f32x2 o0 = v[i][0] * rstd * gm[i][0] + bt[i][0], o1 = v[i][1] * rstd * gm[i][1] + bt[i][1];
-      *(uint2*)(y + row * H + 4 * (lane + 64 * i)) = uint2{pack2(o0), pack2(o1)};
+      const uint2 pk = uint2{pack2(o0), pack2(o1)};
+      *(uint2*)(y + row * H + 4 * (lane + 64 * i)) = pk;
+      if (y8) {   // e4m3 of the bf16 value that was just stored (what a cast of y would give)
+        const f32x2 r0 = unpack2(pk.x), r1 = unpack2(pk.y);
+        const float q[4] = {r0[0], r0[1], r1[0], r1[1]};
+        *(uint32_t*)(y8 + row * H + 4 * (lane + 64 * i)) = fp8_pack4(q);
+      }
     }
     if (lane == 0) *(f32x2*)(stats + 2 * row) = f32x2{mean, rstd};
   }
@@ -653,10 +660,12 @@ extern "C" size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H) {
   return nbest_rowred_ws_bytes(M, H) + (size_t)M * H * sizeof(float);
 }
 
-extern "C" int nbest_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
-                                   int64_t M, int H, float eps, int dtype, nbest_stream_t stream) {
+// y8 != NULL (bf16, H % 256 == 0, H <= 1024 only): also write the e4m3 copy of y that the next fp8 forward GEMM reads
+int nbest_internal_layernorm_fwd8(const void* x, const float* gamma, const float* beta, void* y, void* y8, float* stats,
+                                  int64_t M, int H, float eps, int dtype, nbest_stream_t stream) {
   if (int e = check_h(H)) return e;
   NB_CHECK(x && gamma && beta && y && stats && M > 0, NBEST_ERR_ARG, "layernorm_fwd: null pointer or M <= 0");
+  NB_CHECK(!y8 || (dtype == NBEST_BF16 && H % 256 == 0 && H <= 1024), NBEST_ERR_SHAPE, "layernorm_fwd: fp8 copy needs bf16 and H in {256..1024}");
   hipStream_t st = (hipStream_t)stream;
   const int grid0 = grid_rows(M, 4);
   if (dtype == NBEST_F32) {
@@ -664,16 +673,21 @@ extern "C" int nbest_layernorm_fwd(const void* x, const float* gamma, const floa
   } else if (dtype == NBEST_BF16 && H % 256 == 0 && H <= 1024) {
     const int grid = grid0 < 1024 ? grid0 : 1024;   // 512 ... 4096 blocks tie at 17 us for 100 MB (5.9 TB/s); 8192: 19.5
     switch (H / 256) {
-      case 1: ln_fwd_fast_kernel<1><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps); break;
-      case 2: ln_fwd_fast_kernel<2><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps); break;
-      case 3: ln_fwd_fast_kernel<3><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps); break;
-      default: ln_fwd_fast_kernel<4><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps); break;
+      case 1: ln_fwd_fast_kernel<1><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8); break;
+      case 2: ln_fwd_fast_kernel<2><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8); break;
+      case 3: ln_fwd_fast_kernel<3><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8); break;
+      default: ln_fwd_fast_kernel<4><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8); break;
     }
   } else if (dtype == NBEST_BF16) {
     DISPATCH_VPL(H, (ln_fwd_kernel<bf16, VPL><<<grid0, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, H, eps)));
   } else NB_CHECK(false, NBEST_ERR_DTYPE, "layernorm_fwd: bad dtype %d", dtype);
   NB_LAUNCH_CHECK();
   return NBEST_OK;
+}
+
+extern "C" int nbest_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                   int64_t M, int H, float eps, int dtype, nbest_stream_t stream) {
+  return nbest_internal_layernorm_fwd8(x, gamma, beta, y, nullptr, stats, M, H, eps, dtype, stream);
 }
 
 extern "C" int nbest_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,

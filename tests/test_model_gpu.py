@@ -503,7 +503,7 @@ def test_full_size_batch_additivity(labels):
     assert torch.equal(gf[a.heads_range[0]:a.heads_range[1]], gf2[a.heads_range[0]:a.heads_range[1]])
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "fp8w"])
 def test_training_trajectory_tracks_oracle(dtype, labels):
     """eight optimisation steps (forward, BCE / CE / CLS-MSE losses, backward, BertAdam with warm-up) on changing batches:
     the per-step loss of the HIP path follows the oracle's (fp32 CPU, autograd) step for step"""
@@ -520,7 +520,10 @@ def test_training_trajectory_tracks_oracle(dtype, labels):
     steps, t_total = 8, 10
     om = _oracle_for(cfg, sd, labels)
     oopt = OracleBertAdam(list(om.named_parameters()), lr=2e-4, bert_lr=1e-4, warmup=0.1, t_total=t_total)
-    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0)
+    fp8 = dtype == "fp8w"            # forward GEMMs in fp8; the e4m3 weight copy is re-quantised after every optimizer step
+    if fp8:
+        dtype = torch.bfloat16
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0, fp8_forward=fp8)
     m.load_reference_state(sd)
     m.train()
     opt = HipBertAdam(m, lr=2e-4, bert_lr=1e-4, warmup=0.1, t_total=t_total)
@@ -532,7 +535,7 @@ def test_training_trajectory_tracks_oracle(dtype, labels):
         want.append(float(rec))
         out = train_step(m, opt, {k: torch.from_numpy(v).cuda() for k, v in b.items()}, add_l2_loss=True, add_segment_ids=True)
         got.append(out["loss_parts"].sum().item() / 6)
-    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    tol = 1e-4 if dtype == torch.float32 else (3e-2 if fp8 else 1e-2)      # e4m3 operands: ~5 x the bf16 forward noise
     for s, (w, g) in enumerate(zip(want, got)):
         assert abs(w - g) <= tol * abs(w), (s, w, g, want, got)
     assert want[-1] < want[0]          # and it is actually learning
