@@ -118,8 +118,9 @@ int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream);
  * C[M][N] (bf16) = epi((A8[M][K] . W8[N][K]^T) * out_scale + bias): both operands OCP e4m3 (one byte per element, k-contiguous),
  * on the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; out_scale = 1 / (per-matrix weight scale).
  * Replaces the same nn.Linear forwards as nbest_gemm (installed modeling_bert.py:154-177, 282-293, 325-351); the
- * backward stays on the bf16 kernels.  Epilogues: NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU (writes C = gelu bf16, U = gelu' 8-bit,
- * C8 = e4m3 copy of gelu for the next GEMM), NBEST_EPI_BIAS_DROP_RES.  N % 256 == 0, K % 64 == 0.                      */
+ * weight gradients stay on the bf16 kernels.  Forward epilogues: NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU (writes C = gelu bf16,
+ * U = gelu' 8-bit, C8 = e4m3 copy of gelu for the next GEMM), NBEST_EPI_BIAS_DROP_RES; dgrad epilogues (B = the TRANSPOSED e4m3
+ * weight copy, A = e4m3 gradient copy): NBEST_EPI_NONE, NBEST_EPI_RES, NBEST_EPI_DGELU.  N % 256 == 0, K % 64 == 0.            */
 typedef struct nbest_gemm_fp8_args {
   const void* A;      /* e4m3 [M][lda] */
   const void* B;      /* e4m3 [N][ldb] (the weight matrix as stored, [out][in]) */
@@ -137,7 +138,20 @@ typedef struct nbest_gemm_fp8_args {
   uint64_t seed;
   const float* out_scale_dev; /* optional DEVICE scalar that overrides out_scale (scales produced on the device by
                                  nbest_quantize_weights_fp8: no host round trip) */
+  /* ---- dgrad use (epilogues NONE, RES, DGELU): A8 is the e4m3 copy of a GRADIENT tensor, e4m3(g * s) with
+   * s = 2^floor(log2(224 / amax)) of the amax stored (as float bits) at a_amax; the accumulator is divided by s.
+   * DGELU: C = acc * gelu'(U) in bf16; optional C8 = e4m3(C * s_c), s_c from *c8_amax_prev; *c8_amax_new = max(|C|) (atomic);
+   * optional colsum_out[N] (+)= column sums of C (the FFN-up bias gradient), needs ws >= nbest_gemm_fp8_ws_bytes().   */
+  const uint32_t* a_amax;
+  const uint32_t* c8_amax_prev;
+  uint32_t* c8_amax_new;
+  float* colsum_out;
+  int32_t colsum_accumulate;
+  int32_t pad;
+  void* ws;
+  size_t ws_bytes;
 } nbest_gemm_fp8_args;
+size_t nbest_gemm_fp8_ws_bytes(const nbest_gemm_fp8_args* a);
 int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream);
 /* bf16 [n] -> e4m3 [n], unit scale, saturating at +-448 (activations that feed an fp8 GEMM); n % 8 == 0 */
 int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream);
@@ -261,9 +275,11 @@ typedef struct nbest_matrix_desc {
 } nbest_matrix_desc;
 /* e4m3 copy of the weight matrices (same element offsets, ONE byte per element) from the fp32 master, one scale per
  * matrix: w8 = e4m3(w * 2^floor(log2(224 / max|w|))); inv_scale[i] = 1 / scale of matrix i (device, [n_matrices]).
+ * w8t (optional): the same e4m3 values written transposed ([cols][rows] at the matrix' offset; n_tiles = 64x64 tiles over all
+ * matrices, descs[].tile_start as for nbest_transpose_weights) - the B operand of the fp8 dgrad GEMMs.
  * ws: >= 4 * n_matrices bytes.  Run after every optimizer step, like nbest_transpose_weights.                       */
-int nbest_quantize_weights_fp8(const float* master, void* w8, const nbest_matrix_desc* descs, int n_matrices,
-                               float* inv_scale, void* ws, size_t ws_bytes, nbest_stream_t stream);
+int nbest_quantize_weights_fp8(const float* master, void* w8, void* w8t, const nbest_matrix_desc* descs, int n_matrices,
+                               int n_tiles, float* inv_scale, void* ws, size_t ws_bytes, nbest_stream_t stream);
 int nbest_transpose_weights(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_tiles,
                             nbest_stream_t stream);
 /* fp32 -> bf16 copy of an arena (initial compute copy / after loading a checkpoint) */
@@ -302,6 +318,16 @@ typedef struct nbest_encoder_desc {
    * e4m3 with unit scale on the way in); everything else, and the whole backward, is the bf16 path.                      */
   const void* w8;
   const float* w8_inv_scale;
+  /* optional fp8 dgrads (needs w8): transposed e4m3 weight copy and the per-(layer, tensor) gradient amax history, uint32
+   * float bits [4 L]: index 4 l + {0: FFN-down input gradient, 1: FFN-up input gradient (after GELU'), 2: attention-out
+   * input gradient, 3: dQ|dK|dV}.  The backward always RECORDS this pass's amax into gamax_new (when non-NULL); with
+   * fp8_bwd != 0 the producers also write e4m3 copies scaled from gamax_prev and the four dgrad GEMMs of a layer run on the
+   * fp8 MFMA.  The caller swaps prev/new between passes and sets fp8_bwd only once a history exists.                      */
+  const void* w8t;
+  const uint32_t* gamax_prev;
+  uint32_t* gamax_new;
+  int32_t fp8_bwd;
+  int32_t pad2;
 } nbest_encoder_desc;
 size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
 size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);

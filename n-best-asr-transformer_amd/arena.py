@@ -107,7 +107,7 @@ class ParamArena:
         # transposed bf16 copy of the per-layer weight matrices (same offsets): the dgrad GEMMs read it so both of
         # their operands are k-contiguous.  Only allocated on a GPU (the kernel that fills it is HIP).
         self.w16t = None
-        self.w8 = self.w8_inv_scale = self._w8_ws = None
+        self.w8 = self.w8t = self.w8_inv_scale = self._w8_ws = self.gamax = None
         self._tdescs = None
         if self.w16 is not None and self.device.type == "cuda":
             self.w16t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
@@ -154,9 +154,10 @@ class ParamArena:
             hb.check(hb.lib().nbest_transpose_weights(hb.ptr(self.w16), hb.ptr(self.w16t), hb.ptr(d), n, t, hb.stream_ptr()),
                      "transpose_weights")
         if self.w8 is not None:
-            d, n, _ = self._tdescs
-            hb.check(hb.lib().nbest_quantize_weights_fp8(hb.ptr(self.p), hb.ptr(self.w8), hb.ptr(d), n, hb.ptr(self.w8_inv_scale),
-                                                         hb.ptr(self._w8_ws), self._w8_ws.numel(), hb.stream_ptr()), "quantize_weights_fp8")
+            d, n, t = self._tdescs
+            hb.check(hb.lib().nbest_quantize_weights_fp8(hb.ptr(self.p), hb.ptr(self.w8), hb.ptr(self.w8t), hb.ptr(d), n, t,
+                                                         hb.ptr(self.w8_inv_scale), hb.ptr(self._w8_ws), self._w8_ws.numel(),
+                                                         hb.stream_ptr()), "quantize_weights_fp8")
 
     def enable_fp8_forward(self):
         """allocate the e4m3 weight copy (one byte per element at the arena's element offsets) and its per-matrix inverse
@@ -166,6 +167,9 @@ class ParamArena:
         if self.w8 is None:
             n = self._tdescs[1]
             self.w8 = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
+            self.w8t = torch.zeros(self.total, dtype=torch.uint8, device=self.device)      # transposed: B operand of the fp8 dgrads
+            # gradient amax history of the fp8 dgrads (float bits), two generations swapped by the model after every backward
+            self.gamax = [torch.zeros(n, dtype=torch.int32, device=self.device) for _ in range(2)]
             self.w8_inv_scale = torch.ones(n, dtype=torch.float32, device=self.device)
             self._w8_ws = torch.zeros(4 * n + 16, dtype=torch.uint8, device=self.device)
             self.refresh_transposed()

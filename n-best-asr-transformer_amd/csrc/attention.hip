@@ -175,7 +175,8 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
 // write a wave's [32][64] fp32 accumulator pair (columns 0-31 / 32-63; lane = column) into rows
 // row0.. of a plain [rows][64] bf16 LDS image, then store those 32 rows with 16-byte accesses.
 __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0, const f32x16& o1, int lane, bf16* gbase,
-                                           int64_t gld, int rows_valid, uint8_t* g8 = nullptr) {   // g8: optional e4m3 copy
+                                           int64_t gld, int rows_valid, uint8_t* g8 = nullptr, float s8 = 1.f,
+                                           float* amax = nullptr) {   // g8: optional e4m3 copy of (tile * s8); amax: running max |tile|
   const int hh = lane >> 5, c = lane & 31;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -190,12 +191,20 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
     if (row < rows_valid) {
       const i32x4 v = *(const i32x4*)(img + (row0 + row) * 128 + ch * 16);
       *(i32x4*)(gbase + (int64_t)row * gld + ch * 8) = v;
-      if (g8) {
+      if (g8 || amax) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, v);
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = (float)b[e];
-        *(i32x2*)(g8 + (int64_t)row * gld + ch * 8) = i32x2{(int)fp8_pack4(f), (int)fp8_pack4(f + 4)};
+        if (amax) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) *amax = fmaxf(*amax, fabsf(f[e]));
+        }
+        if (g8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= s8;
+          *(i32x2*)(g8 + (int64_t)row * gld + ch * 8) = i32x2{(int)fp8_pack4(f), (int)fp8_pack4(f + 4)};
+        }
       }
     }
   }
@@ -478,7 +487,7 @@ template <int NKB>
 __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_kernel(
     const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask, const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
     const float* __restrict__ lse, bf16* __restrict__ dqkv, float* __restrict__ colpart, int S, int heads, int H, float scale,
-    DropCfg drop) {
+    DropCfg drop, Fp8Grad f8) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int Sp = NKB * 32;
   constexpr int NW = (NKB <= 4) ? 4 : 8, NT = NW * 64;
@@ -620,10 +629,19 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
   }
   if (wave < NKB) {
     const int r0 = 32 * wave;      // wave w holds dQ of query block w (w = qb mod NW, NKB <= NW) and dK/dV of key block w
-    bf16* g = dqkv + ((int64_t)b * S + r0) * ld + h * 64;
-    store_tile(Qt, r0, dq0, dq1, lane, g, ld, S - r0);
-    store_tile(Kt, r0, dk0, dk1, lane, g + H, ld, S - r0);
-    store_tile(dOt, r0, dv0, dv1, lane, g + 2 * H, ld, S - r0);
+    const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
+    bf16* g = dqkv + goff;
+    uint8_t* g8 = f8.out8 ? f8.out8 + goff : nullptr;
+    const float s8 = fp8_grad_scale(f8.amax_prev);
+    float amax8 = 0.f;
+    float* am = f8.amax_new ? &amax8 : nullptr;
+    store_tile(Qt, r0, dq0, dq1, lane, g, ld, S - r0, g8, s8, am);
+    store_tile(Kt, r0, dk0, dk1, lane, g + H, ld, S - r0, g8 ? g8 + H : nullptr, s8, am);
+    store_tile(dOt, r0, dv0, dv1, lane, g + 2 * H, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, am);
+    if (f8.amax_new) {
+      amax8 = wave_max(amax8);
+      if (lane == 0) amax_update(f8.amax_new, amax8);
+    }
   }
 }
 
@@ -764,9 +782,12 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
                                                                  const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
                                                                  const float* __restrict__ lse, bf16* __restrict__ dqkv,
                                                                  float* __restrict__ colpart, int S, int nkb, int heads, int H,
-                                                                 float scale, DropCfg drop) {
+                                                                 float scale, DropCfg drop, Fp8Grad f8) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int NW = 8, NT = 512, KH = 256, RS = 512;   // keys per half; dS slab row stride (256 keys x 2 B)
+  constexpr int NW = 8, NT = 512, KH = 256, RS = 512;
+  const float s8 = fp8_grad_scale(f8.amax_prev);
+  float amax8 = 0.f;
+  float* am = f8.amax_new ? &amax8 : nullptr;   // keys per half; dS slab row stride (256 keys x 2 B)
   const int Sp = nkb * 32;
   char* Qs = lds;                                       // [2][32][128 B]
   char* dOs = Qs + 2 * 4096;                            // [2][32][128 B]
@@ -900,9 +921,11 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) { ck0 += dk0[r]; ck1 += dk1[r]; cv0 += dv0[r]; cv1 += dv1[r]; }
       const int r0 = key0 + 32 * wave;
-      bf16* g = dqkv + ((int64_t)b * S + r0) * ld + h * 64;
-      store_tile(Kt + wave * 4096, 0, dk0, dk1, lane, g + H, ld, S - r0);
-      store_tile(Kt + wave * 4096, 0, dv0, dv1, lane, g + 2 * H, ld, S - r0);
+      const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
+      bf16* g = dqkv + goff;
+      uint8_t* g8 = f8.out8 ? f8.out8 + goff : nullptr;
+      store_tile(Kt + wave * 4096, 0, dk0, dk1, lane, g + H, ld, S - r0, g8 ? g8 + H : nullptr, s8, am);
+      store_tile(Kt + wave * 4096, 0, dv0, dv1, lane, g + 2 * H, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, am);
     }
   }
   __syncthreads();
@@ -930,11 +953,17 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
   // dQ: wave w holds query blocks w and w + 8
   if (wave < nkb) {
     const int r0 = 32 * wave;
-    store_tile(Kt + wave * 4096, 0, dqa0, dqa1, lane, dqkv + ((int64_t)b * S + r0) * ld + h * 64, ld, S - r0);
+    const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
+    store_tile(Kt + wave * 4096, 0, dqa0, dqa1, lane, dqkv + goff, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, am);
   }
   if (wave + 8 < nkb) {
     const int r0 = 32 * (wave + 8);
-    store_tile(Kt + wave * 4096, 0, dqb0, dqb1, lane, dqkv + ((int64_t)b * S + r0) * ld + h * 64, ld, S - r0);
+    const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
+    store_tile(Kt + wave * 4096, 0, dqb0, dqb1, lane, dqkv + goff, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, am);
+  }
+  if (f8.amax_new) {
+    amax8 = wave_max(amax8);
+    if (lane == 0) amax_update(f8.amax_new, amax8);
   }
 }
 
@@ -944,10 +973,10 @@ static size_t bwd2_lds_bytes(int nkb) {
 }
 template <int NKB>
 static void launch_bwd2(const bf16* qkv, const uint8_t* mask, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv,
-                        float* colpart, int B, int S, int heads, int H, float scale, DropCfg d, hipStream_t st) {
+                        float* colpart, int B, int S, int heads, int H, float scale, DropCfg d, hipStream_t st, Fp8Grad f8) {
   const size_t sm = bwd2_lds_bytes(NKB);
   (void)hipFuncSetAttribute((const void*)attn_bwd2_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  attn_bwd2_bf16_kernel<NKB><<<B * heads, (NKB <= 4 ? 4 : 8) * 64, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d);
+  attn_bwd2_bf16_kernel<NKB><<<B * heads, (NKB <= 4 ? 4 : 8) * 64, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d, f8);
 }
 
 static size_t fwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * 256 + (size_t)nkb * 32 * 4 + 4 * 4096; }
@@ -1026,9 +1055,10 @@ extern "C" size_t nbest_attention_bwd_ws_bytes(int B, int S, int heads) {
   return a > b ? a : b;
 }
 
-extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
-                                   void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
-                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
+// f8 (bf16 only): e4m3 copy (scaled by the previous pass's amax) + amax of dqkv for the fp8 QKV dgrad GEMM
+int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
+                                  void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, Fp8Grad f8) {
   NB_CHECK(qkv && key_mask && ctx && dctx && lse && dqkv, NBEST_ERR_ARG, "attention_bwd: null pointer");
   if (int e = check_common("attention_bwd", B, S, heads, d, dtype)) return e;
   NB_CHECK(!dbias || (ws && ws_bytes >= nbest_attention_bwd_ws_bytes(B, S, heads)), NBEST_ERR_WORKSPACE,
@@ -1054,7 +1084,7 @@ extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, con
     const size_t sm = (size_t)2 * 4096 * 2 + 256 * 128 + 2 * 32 * 512 + (size_t)nkb * 32 * 8;
     (void)hipFuncSetAttribute((const void*)attn_bwd_long_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     attn_bwd_long_bf16_kernel<<<B * heads, 512, sm, st>>>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse,
-                                                         (bf16*)dqkv, colpart, S, nkb, heads, H, scale, dc);
+                                                         (bf16*)dqkv, colpart, S, nkb, heads, H, scale, dc, f8);
     NB_LAUNCH_CHECK();
     if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
     return NBEST_OK;
@@ -1071,10 +1101,17 @@ extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, con
     return NBEST_OK;
   }
 #endif
-#define F(N) case N: launch_bwd2<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st); break;
+#define F(N) case N: launch_bwd2<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st, f8); break;
   switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
 #undef F
   NB_LAUNCH_CHECK();
   if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
   return NBEST_OK;
+}
+
+extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
+                                   void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
+                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
+  return nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, dqkv, dbias, accumulate, ws, ws_bytes, B, S, heads, d, dtype, drop_p,
+                                       seed, drop_stream, stream, Fp8Grad{nullptr, nullptr, nullptr});
 }

@@ -201,6 +201,24 @@ __device__ __forceinline__ uint32_t fp8_pack4(const float* v) {
   return (uint32_t)w;
 }
 
+// fp8 copy of a GRADIENT tensor for the fp8 dgrad GEMMs: e4m3(g * s) with the per-tensor power-of-two scale
+// s = 2^floor(log2(224 / amax)) taken from the amax the SAME tensor had in the previous backward pass (delayed scaling);
+// the producer also records this pass's amax (bits of a non-negative float order like the float).  All-null = off.
+struct Fp8Grad {
+  uint8_t* out8;
+  const uint32_t* amax_prev;
+  uint32_t* amax_new;
+};
+__host__ __device__ __forceinline__ float fp8_scale_of(float amax) { return amax > 0.f ? exp2f(floorf(log2f(224.f / amax))) : 1.f; }
+__device__ __forceinline__ float fp8_grad_scale(const uint32_t* amax_prev) { return amax_prev ? fp8_scale_of(__uint_as_float(*amax_prev)) : 1.f; }
+// *p = max(*p, v) for one lane of a wave.  Thousands of waves update the same word: an unconditional atomicMax from each
+// serialises at the L2 (measured: +66 us on a 126 us kernel for 12 288 atomics); reading first lets all but the few waves
+// that actually raise the maximum skip the atomic.
+__device__ __forceinline__ void amax_update(uint32_t* p, float v) {
+  const uint32_t b = __float_as_uint(v);
+  if (b > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, b);
+}
+
 // ---- counter-based dropout ---------------------------------------------------------------------
 // keep-decision for element `idx` of stream `stream` under (seed): 16-bit uniform compared with a
 // 16-bit threshold.  thr16 = round(p * 65536); the effective drop probability is thr16/65536 and

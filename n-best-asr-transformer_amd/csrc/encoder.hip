@@ -14,6 +14,14 @@
 
 int nbest_internal_layernorm_fwd8(const void* x, const float* gamma, const float* beta, void* y, void* y8, float* stats,
                                   int64_t M, int H, float eps, int dtype, nbest_stream_t stream);
+int nbest_internal_layernorm_bwd8(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                                  void* dx_drop, float* dgamma, float* dbeta, float* dbias, int64_t M, int H, int dtype,
+                                  int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
+                                  size_t ws_bytes, nbest_stream_t stream, Fp8Grad f8);
+int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
+                                  void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, Fp8Grad f8);
+int nbest_internal_amax_bf16(const void* x, int64_t n, uint32_t* out, hipStream_t st);
 int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void* ctx, void* ctx8, float* lse, int B, int S, int heads,
                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream);
 
@@ -97,7 +105,8 @@ static WsLayout ws_layout(const nbest_encoder_desc* d) {
   w.emb_bytes = al(nbest_embed_bwd_ws_bytes(M, d->H));
   w.emb = o; o += w.emb_bytes;
   // fp8 forward: e4m3 copies of the GEMM inputs of ONE layer (x | ctx | x1: [M][H] bytes each, gelu(u): [M][F] bytes)
-  w.f8_bytes = (d->dtype == NBEST_BF16) ? 3 * al((size_t)M * d->H) + al((size_t)M * d->F) : 0;
+  // (backward, fp8 dgrads: dQ|dK|dV copy over the first three blocks, FFN gradient copy over the fourth, a fifth [M][H] block)
+  w.f8_bytes = (d->dtype == NBEST_BF16) ? 4 * al((size_t)M * d->H) + al((size_t)M * d->F) : 0;
   w.f8 = o; o += w.f8_bytes;
   w.total = o;
   return w;
@@ -264,6 +273,28 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     ev_i += which;
   };
 
+  // fp8 dgrads (descriptor: w8t, gamax_prev / gamax_new, fp8_bwd): the gradient amax of every dgrad operand is recorded in
+  // every pass; with a history (fp8_bwd) the producers also write e4m3 copies and the four dgrad GEMMs of a layer run in fp8
+  const bool rec = d->gamax_new && dt == NBEST_BF16;
+  const bool f8b = rec && d->fp8_bwd && d->w8t && d->w8_inv_scale && d->gamax_prev;
+  uint8_t* dqkv8 = f8b ? (uint8_t*)W + w.f8 : nullptr;                       // [M][3H]
+  uint8_t* dBig8 = f8b ? dqkv8 + 3 * al((size_t)M * H) : nullptr;            // [M][F]
+  uint8_t* dRd8 = f8b ? dBig8 + al((size_t)M * F) : nullptr;                 // [M][H]
+  auto fg = [&](uint8_t* out8, int idx) -> Fp8Grad {
+    if (!rec) return Fp8Grad{nullptr, nullptr, nullptr};
+    return Fp8Grad{f8b ? out8 : nullptr, f8b ? d->gamax_prev + idx : nullptr, d->gamax_new + idx};
+  };
+  auto dgrad8 = [&](const uint8_t* A8, int a_idx, int64_t w_off, int mat, void* Cout, int64_t N, int64_t K, int epi, const void* R,
+                    void* U, uint8_t* C8, int c_idx, float* colsum) -> int {
+    nbest_gemm_fp8_args g = {};
+    g.A = A8; g.B = (const uint8_t*)d->w8t + w_off; g.C = Cout; g.R = R; g.U = U; g.C8 = C8;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N; g.ldu = N; g.ldc8 = N;
+    g.epilogue = epi; g.out_scale = 1.f; g.out_scale_dev = d->w8_inv_scale + mat; g.a_amax = d->gamax_prev + a_idx;
+    if (c_idx >= 0) { g.c8_amax_prev = d->gamax_prev + c_idx; g.c8_amax_new = d->gamax_new + c_idx; }
+    g.colsum_out = colsum; g.colsum_accumulate = accumulate; g.ws = red; g.ws_bytes = w.red_bytes;
+    return nbest_gemm_fp8(&g, stream);
+  };
+
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const nbest_layer_offsets& o = d->layers_host[l];
     char* Lb = A + a.layer0 + (size_t)l * a.layer_stride;
@@ -272,36 +303,44 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     void* u = Lb + a.o_u; void* hact = Lb + a.o_hact; void* r2 = Lb + a.o_r2; float* st2 = (float*)(Lb + a.o_st2);
     const uint32_t s0 = sb + 1 + 4 * l;
     // LN2 backward: dR (residual branch), dRd (dense branch, under the dropout mask), db2
-    RUN(nbest_layernorm_bwd(dA, r2, st2, P.P(o.ln2_g), dR, hdrop ? dRd : nullptr, G(o.ln2_g), G(o.ln2_b), G(o.b2), M, H, dt, accumulate,
-                            d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream));
+    RUN(nbest_internal_layernorm_bwd8(dA, r2, st2, P.P(o.ln2_g), dR, hdrop ? dRd : nullptr, G(o.ln2_g), G(o.ln2_b), G(o.b2), M, H, dt,
+                                      accumulate, d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream, fg(dRd8, 4 * l + 0)));
     // FFN-down: dgrad fused with GELU' -> dU ; wgrad
     // (the FFN-up bias gradient = column sums of dU is fused into this epilogue)
-    RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red, w.red_bytes, accumulate,
-             0.f, 0, 0, st, G(o.b1)));
+    if (f8b) {
+      RUN(dgrad8(dRd8, 4 * l + 0, o.w2, 4 * l + 3, dBig, F, H, NBEST_EPI_DGELU, nullptr, u, dBig8, 4 * l + 1, G(o.b1)));
+    } else {
+      RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red, w.red_bytes, accumulate,
+               0.f, 0, 0, st, G(o.b1)));
+      if (rec) RUN(nbest_internal_amax_bf16(dBig, M * F, d->gamax_new + 4 * l + 1, st));   // calibration pass: this producer is a bf16 kernel
+    }
     stamp(0);
     RUN(gemm(dt, dRd, hact, G(o.w2), H, F, M, H, F, F, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
     stamp(1);
     // FFN-up: dgrad + residual gradient ; wgrad
-    RUN(gemm(dt, dBig, PT.W(o.w1), dB1, M, H, F, F, wt ? F : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    if (f8b) RUN(dgrad8(dBig8, 4 * l + 1, o.w1, 4 * l + 2, dB1, H, F, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
+    else RUN(gemm(dt, dBig, PT.W(o.w1), dB1, M, H, F, F, wt ? F : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     stamp(0);
     RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
     stamp(1);
     // LN1 backward
-    RUN(nbest_layernorm_bwd(dB1, r1, st1, P.P(o.ln1_g), dR, hdrop ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt, accumulate,
-                            d->hidden_drop, d->seed, s0 + 1, red, w.red_bytes, stream));
+    RUN(nbest_internal_layernorm_bwd8(dB1, r1, st1, P.P(o.ln1_g), dR, hdrop ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt,
+                                      accumulate, d->hidden_drop, d->seed, s0 + 1, red, w.red_bytes, stream, fg(dRd8, 4 * l + 2)));
     // attention output projection: dgrad ; wgrad
-    RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    if (f8b) RUN(dgrad8(dRd8, 4 * l + 2, o.wo, 4 * l + 1, dctx, H, H, NBEST_EPI_NONE, nullptr, nullptr, nullptr, -1, nullptr));
+    else RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     stamp(0);
     RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
              accumulate, 0.f, 0, 0, st));
     stamp(1);
     // attention backward -> dqkv ; QKV bias gradient
-    RUN(nbest_attention_bwd(qkv, key_mask, ctx, dctx, lse, dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64, dt,
-                            d->attn_drop, d->seed, s0 + 0, stream));
+    RUN(nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64,
+                                      dt, d->attn_drop, d->seed, s0 + 0, stream, fg(dqkv8, 4 * l + 3)));
     // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
-    RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    if (f8b) RUN(dgrad8(dqkv8, 4 * l + 3, o.wqkv, 4 * l + 0, dA, H, 3 * H, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
+    else RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     stamp(0);
     RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
              w.slab_bytes, accumulate, 0.f, 0, 0, st));

@@ -28,6 +28,9 @@ struct GemmP8 {
   uint32_t a_bytes, b_bytes;
   float out_scale;
   const float* out_scale_dev;
+  const uint32_t* a_amax;      // dgrad: A8 = e4m3(gradient * s), s from this amax (fp8_scale_of): the accumulator is divided by s
+  Fp8Grad c8g;                 // DGELU: e4m3 copy of the output gradient (scaled by ITS previous amax) + its new amax
+  float* colpart;              // DGELU: fused column sums of the output (bias gradient), partial rows [tiles_m * 2][N]
   DropCfg drop;
 };
 
@@ -74,18 +77,29 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
 
-  constexpr bool kHasR = (EPI == NBEST_EPI_BIAS_DROP_RES);
+  constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES);
+  constexpr bool kHasR = (EPI == NBEST_EPI_BIAS_DROP_RES || EPI == NBEST_EPI_RES);
+  constexpr bool kHasUin = (EPI == NBEST_EPI_DGELU);
   const int64_t en8 = n0 + wn * WTN + (lane & 7) * 8;
   const int64_t erow0 = m0 + wm * WTM + (lane >> 3);
-  const f32x4 pb0 = *(const f32x4*)(p.bias + en8), pb1 = *(const f32x4*)(p.bias + en8 + 4);
-  const float oscale = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;
-  i32x4 pre[TMb][4];
-  if (kHasR) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int64_t m = erow0 + it * 8;
-      pre[0][it] = (m < p.M) ? *(const i32x4*)(p.R + m * p.ldr + en8) : i32x4{0, 0, 0, 0};
+  f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
+  if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
+  float oscale = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;
+  if (p.a_amax) oscale /= fp8_scale_of(__uint_as_float(*p.a_amax));
+  const float c8s = fp8_grad_scale(p.c8g.amax_prev);
+  float amax8 = 0.f;
+  auto load_pre = [&](int64_t m) -> i32x4 {   // residual rows: bf16, 16 bytes per lane; GELU' rows: 8-bit, 8 bytes per lane
+    if constexpr (kHasR) {
+      return (m < p.M) ? *(const i32x4*)(p.R + m * p.ldr + en8) : i32x4{0, 0, 0, 0};
+    } else {
+      const i32x2 q = (m < p.M) ? *(const i32x2*)(p.U + m * p.ldu + en8) : i32x2{0, 0};
+      return i32x4{q[0], q[1], 0, 0};
     }
+  };
+  i32x4 pre[TMb][4];
+  if (kHasR || kHasUin) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) pre[0][it] = load_pre(erow0 + it * 8);
   }
 
   f32x16 acc[TMb][TNb];
@@ -156,14 +170,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
 
   // ---- epilogue: 32-row blocks restaged through wave-private LDS ([32][64] fp32, chunk16 ^= row & 15) ----
   float* ep = (float*)lds + wave * 2048;
-  if (kHasR) {
+  float colacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (kHasR || kHasUin) {
 #pragma unroll
     for (int c = 1; c < TMb; ++c)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int64_t m = erow0 + c * 32 + it * 8;
-        pre[c][it] = (m < p.M) ? *(const i32x4*)(p.R + m * p.ldr + en8) : i32x4{0, 0, 0, 0};
-      }
+      for (int it = 0; it < 4; ++it) pre[c][it] = load_pre(erow0 + c * 32 + it * 8);
   }
   __builtin_amdgcn_s_barrier();   // every wave has finished reading the operand ring
   asm volatile("" ::: "memory");
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
       if (m >= p.M) continue;
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = fmaf(v[e], oscale, pb0[e]); v[4 + e] = fmaf(v[4 + e], oscale, pb1[e]); }
+      for (int e = 0; e < 4; ++e) { v[e] = fmaf(v[e], oscale, pb0[e]); v[4 + e] = fmaf(v[4 + e], oscale, pb1[e]); }   // (no bias: pb = 0)
       if (EPI == NBEST_EPI_BIAS_GELU) {
         float gp[8];
 #pragma unroll
@@ -201,20 +213,54 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
         *(i32x2*)(p.U + m * p.ldu + en8) = i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)};
         *(i32x2*)(p.C8 + m * p.ldc8 + en8) = i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)};
       }
-      if (EPI == NBEST_EPI_BIAS_DROP_RES) {
-        if (p.drop.thr16) {
-          const uint32_t base = (uint32_t)(m * p.N + en8);
-          const uint32_t k = nb_keep4(p.drop, base) | (nb_keep4(p.drop, base + 4) << 4);
+      if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
+        const uint32_t base = (uint32_t)(m * p.N + en8);
+        const uint32_t k = nb_keep4(p.drop, base) | (nb_keep4(p.drop, base + 4) << 4);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
+      }
+      if (kHasR) {
         const bf16x8 r = __builtin_bit_cast(bf16x8, pre[c][it]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
       }
+      if (kHasUin) {   // x GELU'(u); the result is the gradient the FFN-up dgrad / wgrad read: bf16 + (scaled) e4m3 copy + amax
+        float gd[8];
+        gd_unpack4((uint32_t)pre[c][it][0], gd);
+        gd_unpack4((uint32_t)pre[c][it][1], gd + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] *= gd[e]; colacc[e] += v[e]; }
+        if (p.c8g.amax_new) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) amax8 = fmaxf(amax8, fabsf(v[e]));
+          if (p.c8g.out8) {
+            float q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = v[e] * c8s;
+            *(i32x2*)(p.c8g.out8 + m * p.ldc8 + en8) = i32x2{(int)fp8_pack4(q), (int)fp8_pack4(q + 4)};
+          }
+        }
+      }
       Vec8<bf16>::store(p.C + m * p.ldc + en8, v);
     }
     asm volatile("" ::: "memory");
+  }
+  if (kHasUin && p.colpart) {   // fused bias gradient: per-wave column sums -> partial rows (as gemm_bf16_v2.hip)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = colacc[e];
+      x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+      colacc[e] = x;
+    }
+    if ((lane >> 3) == 0) {
+      float* o = p.colpart + ((int64_t)tile_m * 2 + wm) * p.N + en8;
+      *(f32x4*)o = f32x4{colacc[0], colacc[1], colacc[2], colacc[3]};
+      *(f32x4*)(o + 4) = f32x4{colacc[4], colacc[5], colacc[6], colacc[7]};
+    }
+  }
+  if (kHasUin && p.c8g.amax_new) {
+    amax8 = wave_max(amax8);
+    if (lane == 0) amax_update(p.c8g.amax_new, amax8);
   }
 }
 
@@ -253,7 +299,7 @@ __global__ __launch_bounds__(256) void quant_w8_kernel(const float* __restrict__
   const nbest_matrix_desc d = descs[blockIdx.y];
   const int64_t n = (int64_t)d.rows * d.cols;
   const float amax = __uint_as_float(amax_bits[blockIdx.y]);
-  const float scale = (amax > 0.f) ? exp2f(floorf(log2f(224.f / amax))) : 1.f;
+  const float scale = fp8_scale_of(amax);
   if (blockIdx.x == 0 && threadIdx.x == 0) inv_scale[blockIdx.y] = 1.f / scale;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 2048) {
     float v[8];
@@ -264,7 +310,60 @@ __global__ __launch_bounds__(256) void quant_w8_kernel(const float* __restrict__
   }
 }
 
+// the same quantisation, written TRANSPOSED ([cols][rows] at the matrix' offset): the k-contiguous B operand of the dgrads.
+// One launch: block -> (matrix, 64x64 tile) through descs[].tile_start, as transpose_multi_kernel.
+__global__ __launch_bounds__(256) void quant_w8t_kernel(const float* __restrict__ w, uint8_t* __restrict__ w8t,
+                                                        const nbest_matrix_desc* __restrict__ descs, int n,
+                                                        const uint32_t* __restrict__ amax_bits) {
+  __shared__ uint8_t tile[64][68];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const nbest_matrix_desc d = descs[lo];
+  const float scale = fp8_scale_of(__uint_as_float(amax_bits[lo]));
+  const int t = blockIdx.x - d.tile_start, tc = (d.cols + 63) / 64;
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float* src = w + d.offset;
+  uint8_t* o = w8t + d.offset;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    float v[4] = {(r < d.rows && c < d.cols) ? src[(int64_t)r * d.cols + c] * scale : 0.f, 0.f, 0.f, 0.f};
+    tile[ty + 4 * i][tx] = (uint8_t)(fp8_pack4(v) & 0xFFu);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < d.cols && r < d.rows) o[(int64_t)c * d.rows + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+__global__ __launch_bounds__(256) void amax_bf16_kernel(const bf16* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
+  float mx = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 2048) {
+    float v[8];
+    Vec8<bf16>::load(x + i, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(v[e]));
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) amax_update(out, mx);
+}
+
 }  // namespace
+
+// *out = max(*out, max |x|) over a bf16 tensor (calibration pass of the fp8 dgrads: tensors whose producer is a bf16 kernel)
+int nbest_internal_amax_bf16(const void* x, int64_t n, uint32_t* out, hipStream_t st) {
+  int64_t g = (n / 8 + 255) / 256;
+  if (g > 2048) g = 2048;
+  amax_bf16_kernel<<<(int)g, 256, 0, st>>>((const bf16*)x, n, out);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
 
 extern "C" int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream) {
   NB_CHECK(src && dst && n > 0 && n % 8 == 0, NBEST_ERR_ARG, "cast_bf16_to_fp8: bad arguments");
@@ -275,8 +374,8 @@ extern "C" int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbe
   return NBEST_OK;
 }
 
-extern "C" int nbest_quantize_weights_fp8(const float* master, void* w8, const nbest_matrix_desc* descs, int n_matrices,
-                                          float* inv_scale, void* ws, size_t ws_bytes, nbest_stream_t stream) {
+extern "C" int nbest_quantize_weights_fp8(const float* master, void* w8, void* w8t, const nbest_matrix_desc* descs, int n_matrices,
+                                          int n_tiles, float* inv_scale, void* ws, size_t ws_bytes, nbest_stream_t stream) {
   NB_CHECK(master && w8 && descs && inv_scale && ws && n_matrices > 0, NBEST_ERR_ARG, "quantize_weights_fp8: bad arguments");
   NB_CHECK(ws_bytes >= (size_t)n_matrices * sizeof(uint32_t), NBEST_ERR_WORKSPACE, "quantize_weights_fp8: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -285,24 +384,42 @@ extern "C" int nbest_quantize_weights_fp8(const float* master, void* w8, const n
   NB_LAUNCH_CHECK();
   quant_w8_kernel<<<dim3(64, n_matrices), 256, 0, st>>>(master, (uint8_t*)w8, descs, (const uint32_t*)ws, inv_scale);
   NB_LAUNCH_CHECK();
+  if (w8t) {
+    NB_CHECK(n_tiles > 0, NBEST_ERR_ARG, "quantize_weights_fp8: n_tiles");
+    quant_w8t_kernel<<<n_tiles, 256, 0, st>>>(master, (uint8_t*)w8t, descs, n_matrices, (const uint32_t*)ws);
+    NB_LAUNCH_CHECK();
+  }
   return NBEST_OK;
 }
 
+int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
+
+extern "C" size_t nbest_gemm_fp8_ws_bytes(const nbest_gemm_fp8_args* a) {
+  return (a && a->colsum_out) ? (size_t)((a->M + 255) / 256) * 2 * a->N * sizeof(float) : 0;
+}
+
 extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream) {
-  NB_CHECK(a && a->A && a->B && a->C && a->bias, NBEST_ERR_ARG, "gemm_fp8: null pointer");
+  NB_CHECK(a && a->A && a->B && a->C, NBEST_ERR_ARG, "gemm_fp8: null pointer");
   NB_CHECK(a->M > 0 && a->N % 256 == 0 && a->K % BK8 == 0 && a->K >= BK8, NBEST_ERR_SHAPE,
            "gemm_fp8: needs N %% 256 == 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", (long long)a->M, (long long)a->N, (long long)a->K);
   NB_CHECK(a->lda % 16 == 0 && a->ldb % 16 == 0 && a->ldc % 8 == 0, NBEST_ERR_ALIGN, "gemm_fp8: leading dimensions");
   NB_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0, NBEST_ERR_ALIGN,
            "gemm_fp8: pointers must be 16-byte aligned");
   const int epi = a->epilogue;
-  NB_CHECK(epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES, NBEST_ERR_ARG,
-           "gemm_fp8: epilogue %d is not built (forward GEMMs only)", epi);
+  NB_CHECK(epi == NBEST_EPI_NONE || epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES ||
+               epi == NBEST_EPI_DGELU || epi == NBEST_EPI_RES, NBEST_ERR_ARG, "gemm_fp8: epilogue %d is not built", epi);
+  if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)
+    NB_CHECK(a->bias, NBEST_ERR_ARG, "gemm_fp8: epilogue %d needs bias", epi);
   if (epi == NBEST_EPI_BIAS_GELU)
     NB_CHECK(a->U && a->C8 && a->ldu % 8 == 0 && a->ldc8 % 8 == 0 && ((uintptr_t)a->U & 7) == 0 && ((uintptr_t)a->C8 & 7) == 0,
              NBEST_ERR_ARG, "gemm_fp8: BIAS_GELU needs U (8-bit gelu') and C8 (fp8 copy of the output)");
-  if (epi == NBEST_EPI_BIAS_DROP_RES)
-    NB_CHECK(a->R && a->ldr % 8 == 0 && ((uintptr_t)a->R & 15) == 0, NBEST_ERR_ARG, "gemm_fp8: BIAS_DROP_RES needs R");
+  if (epi == NBEST_EPI_BIAS_DROP_RES || epi == NBEST_EPI_RES)
+    NB_CHECK(a->R && a->ldr % 8 == 0 && ((uintptr_t)a->R & 15) == 0, NBEST_ERR_ARG, "gemm_fp8: epilogue %d needs R", epi);
+  if (epi == NBEST_EPI_DGELU) {
+    NB_CHECK(a->U && a->ldu % 8 == 0 && ((uintptr_t)a->U & 7) == 0, NBEST_ERR_ARG, "gemm_fp8: DGELU needs U (8-bit gelu')");
+    NB_CHECK(!a->C8 || (a->ldc8 % 8 == 0 && ((uintptr_t)a->C8 & 7) == 0), NBEST_ERR_ARG, "gemm_fp8: DGELU fp8 output alignment");
+    NB_CHECK(!a->colsum_out || (a->ws && a->ws_bytes >= nbest_gemm_fp8_ws_bytes(a)), NBEST_ERR_WORKSPACE, "gemm_fp8: column-sum workspace too small");
+  }
   GemmP8 p;
   p.A = (const uint8_t*)a->A; p.B = (const uint8_t*)a->B; p.C = (bf16*)a->C; p.bias = a->bias; p.R = (const bf16*)a->R;
   p.U = (uint8_t*)a->U; p.C8 = (uint8_t*)a->C8;
@@ -314,6 +431,9 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
   p.out_scale = a->out_scale;
   p.out_scale_dev = a->out_scale_dev;
+  p.a_amax = a->a_amax;
+  p.c8g = Fp8Grad{epi == NBEST_EPI_DGELU ? (uint8_t*)a->C8 : nullptr, a->c8_amax_prev, a->c8_amax_new};
+  p.colpart = (epi == NBEST_EPI_DGELU && a->colsum_out) ? (float*)a->ws : nullptr;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm_fp8: dropout counter overflow");
   const int grid = p.tiles_m * p.tiles_n;
@@ -324,8 +444,12 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
     (void)hipFuncSetAttribute((const void*)gemm8_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);    \
     gemm8_kernel<E><<<grid, 512, lds_bytes, st>>>(p);                                                                  \
     break;
-  switch (epi) { L8(NBEST_EPI_BIAS) L8(NBEST_EPI_BIAS_GELU) L8(NBEST_EPI_BIAS_DROP_RES) default: break; }
+  switch (epi) {
+    L8(NBEST_EPI_NONE) L8(NBEST_EPI_BIAS) L8(NBEST_EPI_BIAS_GELU) L8(NBEST_EPI_BIAS_DROP_RES) L8(NBEST_EPI_DGELU) L8(NBEST_EPI_RES)
+    default: break;
+  }
 #undef L8
   NB_LAUNCH_CHECK();
+  if (p.colpart) return nbest_internal_partial_rows_sum(p.colpart, p.tiles_m * 2, (int)a->N, a->colsum_out, a->colsum_accumulate, st);
   return NBEST_OK;
 }

@@ -246,10 +246,13 @@ template <int VPL, bool DROP, bool DBIAS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void ln_bwd_fast_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           bf16* __restrict__ dx, bf16* __restrict__ dx_drop,
-                                                          float* __restrict__ part, int64_t M, int rows_per_block, DropCfg drop) {
+                                                          float* __restrict__ part, int64_t M, int rows_per_block, DropCfg drop,
+                                                          Fp8Grad f8) {   // f8: e4m3 copy / amax of the dense-branch gradient
   constexpr int H = VPL * 256;
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [wave][k][e][i][lane]: every wave parks its column sums here
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float s8 = fp8_grad_scale(f8.amax_prev);
+  float amax8 = 0.f;
   f32x2 gm[VPL][2], ag[VPL][2], ab[VPL][2], ad[VPL][2];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
@@ -320,8 +323,19 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_fast_kernel(const bf16* __r
           *(uint2*)(dx_drop + off) = uint2{pack_bf16x2(o[0]), pack_bf16x2(o[1])};
         }
         if (DBIAS) { ad[i][0] += o[0]; ad[i][1] += o[1]; }
+        if (f8.amax_new) {   // o = the gradient the dense-layer dgrad / wgrad GEMMs read (after the dropout mask)
+          amax8 = fmaxf(fmaxf(amax8, fmaxf(fabsf(o[0][0]), fabsf(o[0][1]))), fmaxf(fabsf(o[1][0]), fabsf(o[1][1])));
+          if (f8.out8) {
+            const float q[4] = {o[0][0] * s8, o[0][1] * s8, o[1][0] * s8, o[1][1] * s8};
+            *(uint32_t*)(f8.out8 + off) = fp8_pack4(q);
+          }
+        }
       }
     }
+  }
+  if (f8.amax_new) {
+    amax8 = wave_max(amax8);
+    if (lane == 0) amax_update(f8.amax_new, amax8);
   }
   float* mine = acc + wave * 3 * H;
 #pragma unroll
@@ -690,11 +704,13 @@ extern "C" int nbest_layernorm_fwd(const void* x, const float* gamma, const floa
   return nbest_internal_layernorm_fwd8(x, gamma, beta, y, nullptr, stats, M, H, eps, dtype, stream);
 }
 
-extern "C" int nbest_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
-                                   void* dx_drop, float* dgamma, float* dbeta, float* dbias, int64_t M, int H, int dtype,
-                                   int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
-                                   size_t ws_bytes, nbest_stream_t stream) {
+// f8 (bf16 fast path only): e4m3 copy + amax of the gradient the dense-layer GEMMs read (dx_drop under dropout, else dx)
+int nbest_internal_layernorm_bwd8(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                                  void* dx_drop, float* dgamma, float* dbeta, float* dbias, int64_t M, int H, int dtype,
+                                  int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
+                                  size_t ws_bytes, nbest_stream_t stream, Fp8Grad f8) {
   if (int e = check_h(H)) return e;
+  NB_CHECK(!f8.amax_new || (dtype == NBEST_BF16 && H % 256 == 0 && H <= 1024), NBEST_ERR_SHAPE, "layernorm_bwd: fp8 copy needs bf16 and H in {256..1024}");
   NB_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && ws && M > 0, NBEST_ERR_ARG, "layernorm_bwd: null pointer");
   NB_CHECK(ws_bytes >= nbest_rowred_ws_bytes(M, H), NBEST_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
   const DropCfg d = make_drop(drop_p, seed, drop_stream);
@@ -718,10 +734,10 @@ extern "C" int nbest_layernorm_bwd(const void* dy, const void* x, const float* s
     if (waves == 8) {                                                                                                          \
       (void)hipFuncSetAttribute((const void*)ln_bwd_fast_kernel<V, D, B, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * H * 4); \
       ln_bwd_fast_kernel<V, D, B, 8><<<nblk, 512, 8 * 3 * H * 4, st>>>((const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx,       \
-                                                                       (bf16*)dx_drop, part, M, rpb, d);                       \
+                                                                       (bf16*)dx_drop, part, M, rpb, d, f8);                   \
     } else {                                                                                                                   \
       ln_bwd_fast_kernel<V, D, B, 4><<<nblk, 256, 4 * 3 * H * 4, st>>>((const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx,       \
-                                                                       (bf16*)dx_drop, part, M, rpb, d);                       \
+                                                                       (bf16*)dx_drop, part, M, rpb, d, f8);                   \
     }                                                                                                                          \
   } while (0)
 #define NB_LNB_V(V)                                                     \
@@ -743,6 +759,14 @@ extern "C" int nbest_layernorm_bwd(const void* dy, const void* x, const float* s
   } else NB_CHECK(false, NBEST_ERR_DTYPE, "layernorm_bwd: bad dtype %d", dtype);
   NB_LAUNCH_CHECK();
   return finalize(part, nblk, H, dgamma, accumulate, dbeta, accumulate, dbias, accumulate, st);
+}
+
+extern "C" int nbest_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                                   void* dx_drop, float* dgamma, float* dbeta, float* dbias, int64_t M, int H, int dtype,
+                                   int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
+                                   size_t ws_bytes, nbest_stream_t stream) {
+  return nbest_internal_layernorm_bwd8(dy, x, stats, gamma, dx, dx_drop, dgamma, dbeta, dbias, M, H, dtype, accumulate, drop_p, seed,
+                                       drop_stream, ws, ws_bytes, stream, Fp8Grad{nullptr, nullptr, nullptr});
 }
 
 extern "C" int nbest_colsum(const void* X, float* out, int64_t M, int64_t N, int64_t ld, int dtype, int accumulate,

@@ -21,7 +21,7 @@ EXPORTS = [
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
-    "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
+    "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
 ]
 
 
@@ -40,7 +40,8 @@ class GemmFp8Args(C.Structure):
                 ("C8", C.c_void_p), ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64), ("ldu", C.c_int64), ("ldc8", C.c_int64),
                 ("epilogue", C.c_int32), ("out_scale", C.c_float), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64),
-                ("out_scale_dev", C.c_void_p)]
+                ("out_scale_dev", C.c_void_p), ("a_amax", C.c_void_p), ("c8_amax_prev", C.c_void_p), ("c8_amax_new", C.c_void_p),
+                ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("pad", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
 class LabelSpaceC(C.Structure):
@@ -70,7 +71,8 @@ class EncoderDesc(C.Structure):
                 ("off_emb_ln_g", C.c_int64), ("off_emb_ln_b", C.c_int64),
                 ("layers_host", C.POINTER(LayerOffsets)), ("seed", C.c_uint64), ("drop_stream_base", C.c_uint32),
                 ("wgrad_events_n", C.c_int32), ("wgrad_events", C.POINTER(C.c_void_p)),
-                ("w8", C.c_void_p), ("w8_inv_scale", C.c_void_p)]
+                ("w8", C.c_void_p), ("w8_inv_scale", C.c_void_p), ("w8t", C.c_void_p), ("gamax_prev", C.c_void_p),
+                ("gamax_new", C.c_void_p), ("fp8_bwd", C.c_int32), ("pad2", C.c_int32)]
 
 
 _lib = None
@@ -118,7 +120,9 @@ def lib():
         L.nbest_transpose_weights.argtypes = [vp, vp, vp, i32, i32, vp]
         L.nbest_gemm_fp8.argtypes = [C.POINTER(GemmFp8Args), vp]
         L.nbest_cast_bf16_to_fp8.argtypes = [vp, vp, i64, vp]
-        L.nbest_quantize_weights_fp8.argtypes = [vp, vp, vp, i32, vp, vp, sz, vp]
+        L.nbest_quantize_weights_fp8.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
+        L.nbest_gemm_fp8_ws_bytes.restype = C.c_size_t
+        L.nbest_gemm_fp8_ws_bytes.argtypes = [C.POINTER(GemmFp8Args)]
         L.nbest_last_error.argtypes = [C.c_char_p, sz]
         _lib = L
     return _lib

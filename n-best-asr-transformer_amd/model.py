@@ -76,7 +76,7 @@ class _Pass:
 
 class NBestSTCModel(nn.Module):
     def __init__(self, cfg: EncoderConfig, labels: LabelSpace, device="cuda", compute_dtype=torch.bfloat16, dropout=0.0,
-                 seed=999, fp8_forward=False):
+                 seed=999, fp8_forward=False, fp8_backward=None):
         super().__init__()
         self.cfg, self.labels, self.compute_dtype = cfg, labels, compute_dtype
         self.dropout = float(dropout)                  # --dropout: feature dropout of the STC heads
@@ -85,10 +85,18 @@ class NBestSTCModel(nn.Module):
         # "fp8w" (BASELINE configs[4]): forward GEMMs on the block-scaled fp8 MFMA from an e4m3 copy of the weights; the
         # master weights, the backward and everything between the GEMMs stay as in the bf16 path
         self.fp8_forward = bool(fp8_forward)
+        # ... and the four dgrad GEMMs of every layer from e4m3 copies of their gradient operands, scaled per tensor from the
+        # amax the same tensor had in the previous backward pass (delayed scaling); the first backward pass runs the bf16
+        # dgrads and only records the amax history.  Weight gradients stay bf16 x bf16 -> fp32.
+        self.fp8_backward = self.fp8_forward if fp8_backward is None else bool(fp8_backward)
+        self._gamax_gen = 0                # which of arena.gamax[0/1] holds the previous pass's amax
+        self._gamax_valid = False
         if self.fp8_forward:
             if compute_dtype != torch.bfloat16:
                 raise RuntimeError("nbest_amd: fp8_forward rides on the bf16 path")
             self.arena.enable_fp8_forward()
+        elif self.fp8_backward:
+            raise RuntimeError("nbest_amd: fp8_backward needs fp8_forward (it shares the e4m3 weight copy)")
         self.bert_encoder = _Holder()
         self.clf = _Holder()
         for s in self.arena.slots:
@@ -214,6 +222,11 @@ class NBestSTCModel(nn.Module):
 
     def _backward_pass(self, ps, dcls, accumulate, chunks=None, on_chunk_done=None):
         cfg = self.cfg
+        if self.fp8_backward:
+            a, d = self.arena, ps.desc
+            d.w8t = a.w8t.data_ptr()
+            d.gamax_prev, d.gamax_new = a.gamax[self._gamax_gen].data_ptr(), a.gamax[1 - self._gamax_gen].data_ptr()
+            d.fp8_bwd = int(self._gamax_valid)
         dh = hb.cls_grad_scatter(dcls, ps.B, ps.S, cfg.hidden_size, self.compute_dtype)
         ids, seg, pos, mask = ps.inputs
         L = cfg.num_hidden_layers
@@ -296,6 +309,10 @@ class NBestSTCModel(nn.Module):
                 self._backward_pass(pa, dcls, accumulate=True, chunks=chunks, on_chunk_done=on_chunk_done)
             else:
                 self._backward_pass(pa, dcls, accumulate=accumulate, chunks=chunks, on_chunk_done=on_chunk_done)
+        if need_grad and self.fp8_backward:     # this pass's amax becomes the history of the next one
+            self._gamax_gen = 1 - self._gamax_gen
+            self.arena.gamax[1 - self._gamax_gen].zero_()
+            self._gamax_valid = True
         self.step_counter += 1
         return dict(top=top, bott=bott, final=fin, loss_parts=loss, asr_cls=ha.view(B, S, H)[:, 0, :],
                     trans_cls=None if ht is None else ht.view(B, St, H)[:, 0, :])
@@ -313,4 +330,5 @@ def make_model(opt):
     labels = LabelSpace(opt.top2bottom_dict, list(getattr(opt, "idx2label", []) or []))
     return NBestSTCModel(cfg, labels, device=getattr(opt, "device", "cuda"),
                          compute_dtype=getattr(opt, "compute_dtype", torch.bfloat16), dropout=getattr(opt, "dropout", 0.0),
-                         seed=getattr(opt, "random_seed", 999), fp8_forward=getattr(opt, "fp8_forward", False))
+                         seed=getattr(opt, "random_seed", 999), fp8_forward=getattr(opt, "fp8_forward", False),
+                         fp8_backward=getattr(opt, "fp8_backward", None))

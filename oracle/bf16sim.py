@@ -100,21 +100,39 @@ def _e4m3(x):
     return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
 
 
+def _fp8_scale(t):
+    """per-tensor power-of-two scale of the fp8 copies: 2^floor(log2(224 / max|t|)) (common.h fp8_scale_of)"""
+    a = t.abs().max()
+    return 2.0 ** torch.floor(torch.log2(224.0 / a)) if a > 0 else torch.tensor(1.0)
+
+
 class _Fp8Linear(torch.autograd.Function):
-    """"fp8w" forward GEMM: y = e4m3(x) . e4m3(W * s)^T / s + b with the per-matrix power-of-two scale
-    s = 2^floor(log2(224 / max|W|)) (nbest_quantize_weights_fp8) and unit-scale activations (nbest_cast_bf16_to_fp8); the
-    backward is the bf16 path's (dgrad on the bf16 weight copy, weight gradient from the bf16 activation)."""
+    """"fp8w" GEMMs of one nn.Linear.  Forward: y = e4m3(x) . e4m3(W * s_w)^T / s_w + b (per-matrix scale s_w,
+    nbest_quantize_weights_fp8; unit-scale activations).  Backward: the weight gradient is the bf16 path's (bf16 gradient x
+    bf16 activation -> fp32); the input gradient is, with ``bwd8``, the fp8 dgrad e4m3(g * s_g) / s_g . e4m3(W * s_w) / s_w with
+    the per-tensor gradient scale s_g (the HIP path takes it from the previous pass's amax of the same tensor; the parity test
+    runs the same batch twice, so that is this tensor's own amax), else the bf16 dgrad on the bf16 weight copy."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        s = 2.0 ** torch.floor(torch.log2(224.0 / w.abs().max()))
-        ctx.save_for_backward(x, _r(w))
-        return F.linear(_e4m3(x), _e4m3(w * s)) / s + b
+    def forward(ctx, x, w, b, bwd8, x_is_f32):
+        s = _fp8_scale(w)
+        w8 = _e4m3(w * s) / s
+        ctx.save_for_backward(_r(x) if x_is_f32 else x, w8 if bwd8 else _r(w))
+        ctx.bwd8, ctx.round_dx = bwd8, x_is_f32
+        return F.linear(_e4m3(x), w8) + b
 
     @staticmethod
     def backward(ctx, g):
-        x, w16 = ctx.saved_tensors
-        return g @ w16, (g.reshape(-1, g.shape[-1]).t() @ x.reshape(-1, x.shape[-1])), g.reshape(-1, g.shape[-1]).sum(0)
+        x16, wd = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if ctx.bwd8:
+            sg = _fp8_scale(g2)
+            dx = (_e4m3(g * sg) / sg) @ wd
+        else:
+            dx = g @ wd
+        if ctx.round_dx:
+            dx = _r(dx)
+        return dx, g2.t() @ x16.reshape(-1, x16.shape[-1]), g2.sum(0), None, None
 
 
 class _GeluStoreFp8(torch.autograd.Function):
@@ -141,9 +159,10 @@ def _ln(x, mod):
     return F.layer_norm(x, (x.shape[-1],), mod.weight, mod.bias, mod.eps)
 
 
-def encode(enc, ids, seg, fp8=False):
+def encode(enc, ids, seg, fp8=False, fp8_bwd=False):
     """oracle.encoder.OracleEncoder.forward with bf16 storage (dropout must be off: parity runs use p = 0); ``fp8``: the
-    four forward GEMMs of every layer as the "fp8w" path runs them (e4m3 operands, see _Fp8Linear)"""
+    four forward GEMMs of every layer as the "fp8w" path runs them (e4m3 operands, the Q|K|V projection as ONE [3H, H]
+    matrix with one scale), ``fp8_bwd``: their four dgrads in fp8 as well (see _Fp8Linear)"""
     cfg = enc.cfg
     key_mask = ids > 0                                                     # quirk Q1 (models/model.py:43)
     if seg is None:
@@ -158,51 +177,41 @@ def encode(enc, ids, seg, fp8=False):
     B, S, H = x.shape
     nh = cfg.num_attention_heads
     d = H // nh
-    lin = (lambda inp, m: _Fp8Linear.apply(inp, m.weight, m.bias)) if fp8 else (lambda inp, m: F.linear(inp, rw(m.weight), m.bias))
     for lyr in enc.encoder.layer:
         a = lyr.attention.self
         split = lambda t: t.view(B, S, nh, d).transpose(1, 2)
-        q, k, v = ract(lin(x, a.query)), ract(lin(x, a.key)), ract(lin(x, a.value))
+        ao = lyr.attention.output
+        if fp8:
+            wqkv = torch.cat([a.query.weight, a.key.weight, a.value.weight])
+            bqkv = torch.cat([a.query.bias, a.key.bias, a.value.bias])
+            q, k, v = ract(_Fp8Linear.apply(x, wqkv, bqkv, fp8_bwd, False)).split(H, dim=-1)
+        else:
+            q, k, v = (ract(F.linear(x, rw(m.weight), m.bias)) for m in (a.query, a.key, a.value))
         o = _AttnCore.apply(split(q), split(k), split(v), key_mask, 1.0 / math.sqrt(d))
         ctx = ract(o.transpose(1, 2).reshape(B, S, H))
-        ao = lyr.attention.output
-        r1 = ract(lin(ctx, ao.dense) + x)
-        x1 = ract(_ln(r1, ao.LayerNorm))
         if fp8:
-            # gelu(u) reaches the next GEMM as e4m3 of the fp32 value; the bf16 copy feeds the backward (weight gradient)
-            h32 = _GeluStoreFp8.apply(lin(x1, lyr.intermediate.dense))
-            r2 = ract(_Fp8LinearPre.apply(h32, lyr.output.dense.weight, lyr.output.dense.bias) + x1)
+            r1 = ract(_Fp8Linear.apply(ctx, ao.dense.weight, ao.dense.bias, fp8_bwd, False) + x)
+            x1 = ract(_ln(r1, ao.LayerNorm))
+            # gelu(u) reaches the next GEMM as e4m3 of the fp32 value; its bf16 copy feeds the weight gradient
+            h32 = _GeluStoreFp8.apply(_Fp8Linear.apply(x1, lyr.intermediate.dense.weight, lyr.intermediate.dense.bias, fp8_bwd, False))
+            r2 = ract(_Fp8Linear.apply(h32, lyr.output.dense.weight, lyr.output.dense.bias, fp8_bwd, True) + x1)
         else:
-            hact = _GeluStore.apply(lin(x1, lyr.intermediate.dense))
-            r2 = ract(lin(hact, lyr.output.dense) + x1)
+            r1 = ract(F.linear(ctx, rw(ao.dense.weight), ao.dense.bias) + x)
+            x1 = ract(_ln(r1, ao.LayerNorm))
+            hact = _GeluStore.apply(F.linear(x1, rw(lyr.intermediate.dense.weight), lyr.intermediate.dense.bias))
+            r2 = ract(F.linear(hact, rw(lyr.output.dense.weight), lyr.output.dense.bias) + x1)
         x = ract(_ln(r2, lyr.output.LayerNorm))
     return x[:, 0, :]
 
 
-class _Fp8LinearPre(torch.autograd.Function):
-    """_Fp8Linear whose input arrives in fp32 (gelu(u) straight from the epilogue): forward on e4m3(input), backward on its
-    bf16 copy, gradient to the input rounded to bf16 (the stored dU path)"""
-
-    @staticmethod
-    def forward(ctx, x, w, b):
-        s = 2.0 ** torch.floor(torch.log2(224.0 / w.abs().max()))
-        ctx.save_for_backward(_r(x), _r(w))
-        return F.linear(_e4m3(x), _e4m3(w * s)) / s + b
-
-    @staticmethod
-    def backward(ctx, g):
-        x16, w16 = ctx.saved_tensors
-        return _r(g @ w16), (g.reshape(-1, g.shape[-1]).t() @ x16.reshape(-1, x16.shape[-1])), g.reshape(-1, g.shape[-1]).sum(0)
-
-
-def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, fp8=False):
+def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, fp8=False, fp8_bwd=False):
     """oracle.model.OracleModel.forward (classifier_input_type 'asr') on the bf16-storage encoder; heads in fp32"""
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             assert m.p == 0.0 or not model.training
     if model.family == "xlm-roberta":
         seg_ids = trans_seg_ids = None
-    asr_cls = encode(model.bert_encoder, input_ids, seg_ids, fp8)
-    trans_cls = encode(model.bert_encoder, trans_input_ids, trans_seg_ids, fp8) if trans_input_ids is not None else None
+    asr_cls = encode(model.bert_encoder, input_ids, seg_ids, fp8, fp8_bwd)
+    trans_cls = encode(model.bert_encoder, trans_input_ids, trans_seg_ids, fp8, fp8_bwd) if trans_input_ids is not None else None
     top, bottoms, final = model.clf(asr_cls)
     return top, bottoms, final, asr_cls, trans_cls

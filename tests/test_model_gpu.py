@@ -244,7 +244,7 @@ def test_xlmr_large_shape_matches_oracle(dtype, labels):
     _check_vs_oracle(cfg, 3, 72, 24, dtype, labels)
 
 
-def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False):
+def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False, fp8_bwd=False):
     from nbest_amd import synth
     from nbest_amd.model import NBestSTCModel
     from oracle import bf16sim, stc
@@ -265,7 +265,7 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False):
         # noise floor of THIS case: the same oracle with bf16 storage (oracle/bf16sim.py) against its fp32 self
         for p in om.parameters():
             p.grad = None
-        stop, sbot, sfin, sasr, str_ = bf16sim.forward(om, t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"], fp8=fp8)
+        stop, sbot, sfin, sasr, str_ = bf16sim.forward(om, t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"], fp8=fp8, fp8_bwd=fp8_bwd)
         _, stotal, _ = stc.total_loss(stop, sbot, sfin, t["labels"], labels.top2bottom, b2t, sasr, str_, True)
         stotal.backward()
         fl_top, fl_fin = (stop - top).abs().max().item(), (sfin - final).abs().max().item()
@@ -273,12 +273,15 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False):
         for n, p in om.named_parameters():
             if n in ref_g:
                 sim_ns[n] = ((p.grad - ref_g[n]).norm() / ref_g[n].norm().clamp_min(1e-30)).item()
-    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0, fp8_forward=fp8)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.0, fp8_forward=fp8, fp8_backward=fp8_bwd)
     m.load_reference_state(sd)
     m.train()
     b = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
-    out = m.forward_backward(b["ids"], b["labels"], seg_ids=b["seg"], trans_input_ids=b["tids"], trans_seg_ids=b["tseg"], add_l2_loss=True)
-    tag = "edge %s B=%d S=%d %s " % (cfg.family, B, S, "f32" if f32 else ("fp8w" if fp8 else "bf16"))
+    # fp8 dgrads scale every gradient operand by the amax it had in the PREVIOUS pass: the first pass (bf16 dgrads) only records
+    # that history, the second one on the same batch is the fp8 pass whose scales equal the oracle leg's own-amax scales
+    for _ in range(2 if fp8_bwd else 1):
+        out = m.forward_backward(b["ids"], b["labels"], seg_ids=b["seg"], trans_input_ids=b["tids"], trans_seg_ids=b["tseg"], add_l2_loss=True)
+    tag = "edge %s B=%d S=%d %s " % (cfg.family, B, S, "f32" if f32 else (("fp8w+dgrad" if fp8_bwd else "fp8w-fwd") if fp8 else "bf16"))
     if f32:
         _cmp(tag + "top", out["top"], top.detach(), atol=1e-4)
         _cmp(tag + "final", out["final"], final.detach(), atol=1e-4)
@@ -310,19 +313,21 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False):
         assert torch.equal(m.decode(out["top"], out["bott"]).cpu().long(), dec)
 
 
-@pytest.mark.parametrize("family,B,S,St", [("bert", 3, 40, 12), ("bert", 2, 200, 40), ("xlmr-large", 2, 72, 24)])
-def test_fp8_forward_matches_its_oracle_leg(family, B, S, St, labels):
-    """"fp8w" (BASELINE configs[4]: fp8 weights on the CDNA4 fp8 MFMA): forward GEMMs on v_mfma_scale_f32_32x32x64_f8f6f4 from a
-    per-matrix-scaled e4m3 copy of the weights, activations cast to e4m3 on the way in; backward = the bf16 path.  Bar: the
-    same as for bf16 - within 1.5 x the noise floor of the oracle leg that rounds exactly the same tensors
-    (oracle/bf16sim.py, fp8=True), scores, loss and per-tensor gradient noise-to-signal."""
+@pytest.mark.parametrize("bwd8", [False, True])
+@pytest.mark.parametrize("family,B,S,St", [("bert", 3, 40, 12), ("bert", 2, 200, 40), ("xlmr-large", 2, 72, 24), ("bert", 2, 300, 40)])
+def test_fp8_forward_matches_its_oracle_leg(family, B, S, St, bwd8, labels):
+    """"fp8w" (BASELINE configs[4]: fp8 weights on the CDNA4 fp8 MFMA): forward GEMMs - and with ``bwd8`` the dgrad GEMMs - on
+    v_mfma_scale_f32_32x32x64_f8f6f4 from a per-matrix-scaled e4m3 copy of the weights; activations are cast to e4m3 (unit scale)
+    by their producers, gradient operands to e4m3 with a per-tensor delayed scale; weight gradients, attention, LayerNorm,
+    heads and the optimizer are the bf16 path.  Bar: the same as for bf16 - within 1.5 x the noise floor of the oracle leg that
+    rounds exactly the same tensors (oracle/bf16sim.py, fp8=True[, fp8_bwd=True]): scores, loss, per-tensor gradient noise-to-signal."""
     import nbest_amd  # noqa: F401
     from nbest_amd import config as ncfg
     if family == "bert":
         cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     else:
         cfg = ncfg.xlmr_large(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    _check_vs_oracle(cfg, B, S, St, torch.bfloat16, labels, fp8=True)
+    _check_vs_oracle(cfg, B, S, St, torch.bfloat16, labels, fp8=True, fp8_bwd=bwd8)
 
 
 def test_too_long_sequence_fails_loudly(labels):
