@@ -250,7 +250,7 @@ def main():
         elif a.model == "bert" and a.add_l2_loss and a.seq_len == 256 and a.n_best == 10:
             cfg_label = "BASELINE configs[3] shape"
         elif a.model == "xlm-roberta-large" and a.seq_len == 256:
-            cfg_label = "BASELINE configs[4] shape in bf16 (the fp8-weight path is not built)"
+            cfg_label = "BASELINE configs[4] shape" + ("" if a.dtype == "fp8w" else " in bf16 (configs[4] itself is --dtype fp8w)")
         else:
             cfg_label = "custom shape"
         res = {
@@ -259,9 +259,11 @@ def main():
             "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: %s shape (random init), %s, synthetic n_best=%d seq_len=%d, batch %d per GPU, "
-                                   "fwd+losses+bwd+allreduce+BertAdam%s, dropout %s" % (
+                                   "fwd+losses+bwd+allreduce+BertAdam%s%s, dropout %s" % (
                                        cfg_label, {"bert": "bert-base-uncased", "xlm-roberta": "xlm-roberta-base"}.get(a.model, a.model), a.dtype,
                                        a.n_best, a.seq_len, a.batch, " + transcript pass and CLS-MSE (--add_l2_loss)" if a.add_l2_loss else "",
+                                       "; fp8w = forward and dgrad GEMMs on the block-scaled fp8 MFMA (e4m3 weight copy, e4m3 activation / "
+                                       "gradient copies), weight gradients and everything else bf16" if a.dtype == "fp8w" else "",
                                        "off" if a.no_dropout else "on (0.1/0.1/0.3)"),
                        "global_batch": a.batch * world, "seq_len": a.seq_len, "n_best": a.n_best, "parallelism": "dp%d" % world,
                        "add_l2_loss": bool(a.add_l2_loss)},
