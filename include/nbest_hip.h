@@ -153,6 +153,13 @@ typedef struct nbest_gemm_fp8_args {
 } nbest_gemm_fp8_args;
 size_t nbest_gemm_fp8_ws_bytes(const nbest_gemm_fp8_args* a);
 int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream);
+/* fp8 weight gradient: dW[M][N] (fp32) (+)= sum over K tokens of dY8[k][m] * X8[k][n] / s, both operands TOKEN-major e4m3
+ * ([K][lda] / [K][ldb], as their producers wrote them: the reduction dimension is read through transposed LDS reads),
+ * s = the gradient scale of dY8 (from the float bits at a_amax, NULL = 1).  M, N multiples of 256; split-K over tokens into
+ * ws (>= nbest_wgrad_fp8_ws_bytes) + deterministic reduce.  Replaces the weight-gradient half of the nn.Linear backward. */
+size_t nbest_wgrad_fp8_ws_bytes(int64_t M, int64_t N, int64_t K);
+int nbest_wgrad_fp8(const void* dY8, const void* X8, float* dW, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                    int64_t ldc, const uint32_t* a_amax, int accumulate, void* ws, size_t ws_bytes, nbest_stream_t stream);
 /* bf16 [n] -> e4m3 [n], unit scale, saturating at +-448 (activations that feed an fp8 GEMM); n % 8 == 0 */
 int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream);
 

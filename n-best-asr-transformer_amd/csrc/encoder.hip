@@ -32,6 +32,7 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct ActLayout {
   size_t esz, X, emb_stats, layer0, layer_stride;
   size_t o_qkv, o_ctx, o_lse, o_r1, o_st1, o_x1, o_u, o_hact, o_r2, o_st2;
+  size_t o_x8, o_ctx8, o_x18, o_h8;   // fp8 forward ("fp8w"): e4m3 copies of the four GEMM inputs of the layer, kept for the fp8 weight gradients
   size_t total;
   int64_t M;
 };
@@ -57,6 +58,14 @@ static ActLayout act_layout(const nbest_encoder_desc* d) {
   a.o_hact = p; p += MF;
   a.o_r2 = p; p += MH;
   a.o_st2 = p; p += st;
+  a.o_x8 = a.o_ctx8 = a.o_x18 = a.o_h8 = 0;
+  if (d->w8) {   // only the fp8 mode pays for them (+ (3 H + F) bytes per token and layer)
+    const size_t MH8 = al((size_t)a.M * d->H), MF8 = al((size_t)a.M * d->F);
+    a.o_x8 = p; p += MH8;
+    a.o_ctx8 = p; p += MH8;
+    a.o_x18 = p; p += MH8;
+    a.o_h8 = p; p += MF8;
+  }
   a.layer_stride = p;
   a.total = o + (size_t)d->L * p;
   return a;
@@ -75,6 +84,10 @@ static size_t max_splitk_bytes(const nbest_encoder_desc* d, int64_t M) {
     g.dtype = d->dtype;
     const size_t b = nbest_gemm_ws_bytes(&g);
     if (b > mx) mx = b;
+    if (d->dtype == NBEST_BF16 && shapes[i][0] % 256 == 0 && shapes[i][1] % 256 == 0) {   // fp8 weight gradients: own split plan
+      const size_t b8 = nbest_wgrad_fp8_ws_bytes(shapes[i][0], shapes[i][1], M);
+      if (b8 > mx) mx = b8;
+    }
   }
   return mx;
 }
@@ -183,10 +196,8 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
   RUN(nbest_embed_ln_fwd(ids, seg, pos, P.W(d->off_word), P.W(d->off_type), P.W(d->off_pos), P.P(d->off_emb_ln_g),
                          P.P(d->off_emb_ln_b), X(0), (float*)(A + a.emb_stats), M, H, d->ln_eps, dt, d->hidden_drop, d->seed, sb, st));
   // fp8 forward: the four GEMMs of a layer on the block-scaled fp8 MFMA; their A operands are e4m3 copies in `ws`
-  uint8_t* x8 = f8 ? (uint8_t*)ws + wl.f8 : nullptr;
-  uint8_t* ctx8 = f8 ? x8 + al((size_t)M * H) : nullptr;
-  uint8_t* x18 = f8 ? ctx8 + al((size_t)M * H) : nullptr;
-  uint8_t* h8 = f8 ? x18 + al((size_t)M * H) : nullptr;
+  // (kept per layer in the activation stash: the fp8 weight gradients of the backward read them again)
+  auto L8 = [&](int l, size_t off) -> uint8_t* { return f8 ? (uint8_t*)(A + a.layer0 + (size_t)l * a.layer_stride + off) : nullptr; };
   auto gemm8 = [&](const uint8_t* A8, int64_t w_off, int mat, void* Cout, int64_t N, int64_t K, int epi, const float* bias, const void* R,
                    void* U, uint8_t* C8, float drop_p, uint32_t stream_id) -> int {
     nbest_gemm_fp8_args g = {};
@@ -202,6 +213,8 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     void* r1 = Lb + a.o_r1; float* st1 = (float*)(Lb + a.o_st1); void* x1 = Lb + a.o_x1;
     void* u = Lb + a.o_u; void* hact = Lb + a.o_hact; void* r2 = Lb + a.o_r2; float* st2 = (float*)(Lb + a.o_st2);
     const uint32_t s0 = sb + 1 + 4 * l;
+    uint8_t* x8 = L8(l, a.o_x8); uint8_t* ctx8 = L8(l, a.o_ctx8); uint8_t* x18 = L8(l, a.o_x18); uint8_t* h8 = L8(l, a.o_h8);
+    uint8_t* x8_next = (l + 1 < d->L) ? L8(l + 1, a.o_x8) : nullptr;   // the last LayerNorm's copy has no reader
     // QKV projection: [M,H] x [3H,H]^T + b
     if (f8) {
       if (l == 0) RUN(nbest_cast_bf16_to_fp8(X(0), x8, M * H, stream));   // later layers: written by the previous layer's LayerNorm
@@ -229,7 +242,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     } else
     RUN(gemm(dt, hact, P.W(o.w2), r2, M, H, F, F, F, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.b2), x1, H, nullptr, 0, nullptr, 0, 0,
              d->hidden_drop, d->seed, s0 + 2, st));
-    RUN(nbest_internal_layernorm_fwd8(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), x8, st2, M, H, d->ln_eps, dt, stream));
+    RUN(nbest_internal_layernorm_fwd8(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), x8_next, st2, M, H, d->ln_eps, dt, stream));
   }
   if (hidden_out) *hidden_out = X(d->L);
   return NBEST_OK;
@@ -302,6 +315,8 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     void* r1 = Lb + a.o_r1; float* st1 = (float*)(Lb + a.o_st1); void* x1 = Lb + a.o_x1;
     void* u = Lb + a.o_u; void* hact = Lb + a.o_hact; void* r2 = Lb + a.o_r2; float* st2 = (float*)(Lb + a.o_st2);
     const uint32_t s0 = sb + 1 + 4 * l;
+    const uint8_t* x8 = (const uint8_t*)(Lb + a.o_x8); const uint8_t* ctx8 = (const uint8_t*)(Lb + a.o_ctx8);
+    const uint8_t* x18 = (const uint8_t*)(Lb + a.o_x18); const uint8_t* h8 = (const uint8_t*)(Lb + a.o_h8);
     // LN2 backward: dR (residual branch), dRd (dense branch, under the dropout mask), db2
     RUN(nbest_internal_layernorm_bwd8(dA, r2, st2, P.P(o.ln2_g), dR, hdrop ? dRd : nullptr, G(o.ln2_g), G(o.ln2_b), G(o.b2), M, H, dt,
                                       accumulate, d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream, fg(dRd8, 4 * l + 0)));
@@ -315,15 +330,17 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
       if (rec) RUN(nbest_internal_amax_bf16(dBig, M * F, d->gamax_new + 4 * l + 1, st));   // calibration pass: this producer is a bf16 kernel
     }
     stamp(0);
-    RUN(gemm(dt, dRd, hact, G(o.w2), H, F, M, H, F, F, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
-             accumulate, 0.f, 0, 0, st));
+    if (f8b) RUN(nbest_wgrad_fp8(dRd8, h8, G(o.w2), H, F, M, H, F, F, d->gamax_prev + 4 * l + 0, accumulate, slab, w.slab_bytes, stream));
+    else RUN(gemm(dt, dRd, hact, G(o.w2), H, F, M, H, F, F, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
+                  accumulate, 0.f, 0, 0, st));
     stamp(1);
     // FFN-up: dgrad + residual gradient ; wgrad
     if (f8b) RUN(dgrad8(dBig8, 4 * l + 1, o.w1, 4 * l + 2, dB1, H, F, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
     else RUN(gemm(dt, dBig, PT.W(o.w1), dB1, M, H, F, F, wt ? F : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     stamp(0);
-    RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
-             accumulate, 0.f, 0, 0, st));
+    if (f8b) RUN(nbest_wgrad_fp8(dBig8, x18, G(o.w1), F, H, M, F, H, H, d->gamax_prev + 4 * l + 1, accumulate, slab, w.slab_bytes, stream));
+    else RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
+                  accumulate, 0.f, 0, 0, st));
     stamp(1);
     // LN1 backward
     RUN(nbest_internal_layernorm_bwd8(dB1, r1, st1, P.P(o.ln1_g), dR, hdrop ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt,
@@ -332,8 +349,9 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     if (f8b) RUN(dgrad8(dRd8, 4 * l + 2, o.wo, 4 * l + 1, dctx, H, H, NBEST_EPI_NONE, nullptr, nullptr, nullptr, -1, nullptr));
     else RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     stamp(0);
-    RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
-             accumulate, 0.f, 0, 0, st));
+    if (f8b) RUN(nbest_wgrad_fp8(dRd8, ctx8, G(o.wo), H, H, M, H, H, H, d->gamax_prev + 4 * l + 2, accumulate, slab, w.slab_bytes, stream));
+    else RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
+                  accumulate, 0.f, 0, 0, st));
     stamp(1);
     // attention backward -> dqkv ; QKV bias gradient
     RUN(nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64,
@@ -342,8 +360,9 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     if (f8b) RUN(dgrad8(dqkv8, 4 * l + 3, o.wqkv, 4 * l + 0, dA, H, 3 * H, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
     else RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     stamp(0);
-    RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
-             w.slab_bytes, accumulate, 0.f, 0, 0, st));
+    if (f8b) RUN(nbest_wgrad_fp8(dqkv8, x8, G(o.wqkv), 3 * H, H, M, 3 * H, H, H, d->gamax_prev + 4 * l + 3, accumulate, slab, w.slab_bytes, stream));
+    else RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
+                  w.slab_bytes, accumulate, 0.f, 0, 0, st));
     stamp(1);
   }
   if (!with_embeddings) return NBEST_OK;

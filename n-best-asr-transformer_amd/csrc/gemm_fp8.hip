@@ -342,6 +342,207 @@ __global__ __launch_bounds__(256) void quant_w8t_kernel(const float* __restrict_
   }
 }
 
+// ---- weight gradient in fp8: dW[Nw][Kw] (fp32) = sum over tokens dY8[m][nw] * X8[m][kw] * out_scale ---------------------------------
+// Both operands are TOKEN-major e4m3 tensors ([M][features], as their producers wrote them), the reduction runs over tokens, so the
+// 32 k-bytes a lane feeds to the MFMA are a COLUMN of the LDS tile: ds_read_b64_tr_b8.  Its semantics (tools/micro/tr8_probe.hip):
+// in a 16-lane group, lane i receives byte (i & 7) of the 8-byte chunks addressed by lanes 2j + (i >> 3), j = 0..7 - an 8x8 byte
+// transpose per lane parity.  With source lane (j, p) of group G pointing at token row 32 (G >> 1) + 8 q + j, feature chunk
+// 16 (G & 1) + 8 p, read q = 0..3 gives lane l tokens 32 (l >> 5) + 8 q .. + 7 of feature (l & 31): the MX operand.
+// LDS image [64 tokens][256 B]: 16-byte chunk index ^= token & 7 (the 8 rows of a transposed read hit 8 different chunks).
+// Same ping-pong schedule and 4-stage ring as gemm8_kernel (a stage = 64 tokens x 256 features per operand = 16 KiB);
+// split-K over tokens into fp32 slabs, reduced by the caller (nbest_internal_splitk_reduce).
+struct GemmP8T {
+  const uint8_t* A; const uint8_t* B; float* C; float* slab;
+  int64_t M, N, K, lda, ldb, ldc;           // M, N: output rows / cols (features of A / of B); K: tokens
+  int64_t k_per_split;
+  int tiles_m, tiles_n, splits, accumulate;
+  uint32_t a_bytes, b_bytes;
+  const uint32_t* a_amax;                    // dY8 = e4m3(dY * s): the accumulator is divided by s
+};
+
+__device__ __forceinline__ void stage_tile8t(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t f0, int64_t k0, int64_t ld, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = i * 512 + tid;                 // 64 token rows x 16 chunks of 16 bytes
+    const int row = p >> 4, slot = p & 15;
+    const int c = slot ^ (row & 7);
+    const uint32_t voff = (uint32_t)((k0 + row) * ld + f0 + c * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * 512 + wave * 64) * 16), 16, voff, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ i32x2 ds_read_tr8_asm(const char* addr) {
+  i32x2 v;
+  const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)addr;
+  asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+
+// features [f0, f0 + 32) x the 64 tokens of the stage -> MX operand (lane l: feature f0 + (l & 31), tokens 32 (l >> 5) .. + 31)
+__device__ __forceinline__ i32x8 read_frag8t(const char* tile, int f0, int lane) {
+  const int G = lane >> 4, i = lane & 15, j = i >> 1, pp = i & 1;
+  const int chunk = (f0 >> 4) + (G & 1);
+  i32x8 out;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 32 * (G >> 1) + 8 * q + j;
+    const i32x2 v = ds_read_tr8_asm(tile + row * 256 + ((chunk ^ (row & 7)) << 4) + 8 * pp);
+    out[2 * q] = v[0]; out[2 * q + 1] = v[1];
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int BM = 256, BN = 256, WN = 4, STAGES = 4;
+  constexpr int WTM = 128, WTN = 64, TMb = 4, TNb = 2;
+  constexpr int A_BYTES = BK8 * BM, STAGE = 2 * A_BYTES;
+  constexpr int NDMA = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int id = xcd_remap8(blockIdx.x, gridDim.x);
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = id / tiles, t = id - z * tiles;
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+  const int64_t kbeg = (int64_t)z * p.k_per_split;
+  const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+  const int nk = (int)((kend - kbeg + BK8 - 1) / BK8);     // token rows past K are zero-filled by the buffer range check
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  const float oscale = p.a_amax ? 1.f / fp8_scale_of(__uint_as_float(*p.a_amax)) : 1.f;
+
+  f32x16 acc[TMb][TNb];
+#pragma unroll
+  for (int i = 0; i < TMb; ++i)
+#pragma unroll
+    for (int j = 0; j < TNb; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int grp = __builtin_amdgcn_readfirstlane(wm);
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0) {
+    if (s0 < nk) {
+      stage_tile8t(rsA, lds + s0 * STAGE, m0, kbeg + (int64_t)s0 * BK8, p.lda, tid);
+      stage_tile8t(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK8, p.ldb, tid);
+    }
+  }
+  {
+    const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
+    if (younger >= 2) wait_vm8<2 * NDMA>();
+    else if (younger == 1) wait_vm8<NDMA>();
+    else wait_vm8<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  i32x8 af[TMb], bfr[TNb];
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + STAGES - 1 < nk) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK8;
+      stage_tile8t(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+      stage_tile8t(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+    }
+    const char* cur = lds + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < TNb; ++j) bfr[j] = read_frag8t(cur + A_BYTES, wn * WTN + j * 32, lane);
+#pragma unroll
+    for (int i = 0; i < TMb; ++i) af[i] = read_frag8t(cur, wm * WTM + i * 32, lane);
+    {
+      const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1;
+      if (c >= 3) wait_vm8<2 * NDMA>();
+      else if (c == 2) wait_vm8<NDMA>();
+      else if (c == 1) wait_vm8<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm reads are invisible to the compiler's wait-count pass
+#pragma unroll
+    for (int i = 0; i < TMb; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+    for (int j = 0; j < TNb; ++j) asm volatile("" : "+v"(bfr[j]));
+#pragma unroll
+    for (int i = 0; i < TMb; ++i)
+#pragma unroll
+      for (int j = 0; j < TNb; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 127, 0, 127);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+
+  float* ep = (float*)lds + wave * 2048;
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const int hh = lane >> 5, wrow = lane & 31;
+  const int64_t en8 = n0 + wn * WTN + (lane & 7) * 8;
+#pragma unroll
+  for (int c = 0; c < TMb; ++c) {
+#pragma unroll
+    for (int j = 0; j < TNb; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cw = 8 * j + 2 * q + hh;
+        *(f32x4*)(ep + wrow * 64 + ((cw ^ (wrow & 15)) << 2)) =
+            f32x4{acc[c][j][4 * q], acc[c][j][4 * q + 1], acc[c][j][4 * q + 2], acc[c][j][4 * q + 3]};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pidx = it * 64 + lane, row = pidx >> 3, c8 = pidx & 7;
+      const int64_t m = m0 + wm * WTM + c * 32 + row;
+      f32x4 v0 = *(const f32x4*)(ep + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
+      f32x4 v1 = *(const f32x4*)(ep + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+      if (m >= p.M) continue;
+      v0 *= oscale; v1 *= oscale;
+      float* cp = (p.splits > 1) ? p.slab + ((int64_t)z * p.M + m) * p.N + en8 : p.C + m * p.ldc + en8;
+      if (p.splits == 1 && p.accumulate) { v0 += *(const f32x4*)cp; v1 += *(const f32x4*)(cp + 4); }
+      *(f32x4*)cp = v0;
+      *(f32x4*)(cp + 4) = v1;
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce8_kernel(const float* __restrict__ slab, float* __restrict__ C, int64_t MN,
+                                                             int64_t N, int64_t ldc, int splits, int accumulate) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    f32x4 s = *(const f32x4*)(slab + i);
+    for (int z = 1; z < splits; ++z) s += *(const f32x4*)(slab + (int64_t)z * MN + i);
+    const int64_t m = i / N, n = i - m * N;
+    float* c = C + m * ldc + n;
+    if (accumulate) s += *(const f32x4*)c;
+    *(f32x4*)c = s;
+  }
+}
+
+static void plan8tt(int64_t M, int64_t N, int64_t K, int* splits, int64_t* kps) {
+  const int64_t tiles = (M / 256) * (N / 256);
+  const int64_t maxs = (K / 512 < 1) ? 1 : ((K / 512 > 32) ? 32 : K / 512);
+  int64_t best_s = 1;
+  double best = -1.0;
+  for (int64_t sp = 1; sp <= maxs; ++sp) {
+    const int64_t blocks = tiles * sp;
+    const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+    if (eff > best + 1e-9) { best = eff; best_s = sp; }
+    if (blocks * 5 >= 256 * 4 && eff >= 0.93) { best_s = sp; break; }
+  }
+  int64_t k = (K + best_s - 1) / best_s;
+  k = (k + 63) / 64 * 64;
+  *splits = (int)((K + k - 1) / k);
+  *kps = k;
+}
+
 __global__ __launch_bounds__(256) void amax_bf16_kernel(const bf16* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
   float mx = 0.f;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 2048) {
@@ -362,6 +563,45 @@ int nbest_internal_amax_bf16(const void* x, int64_t n, uint32_t* out, hipStream_
   if (g > 2048) g = 2048;
   amax_bf16_kernel<<<(int)g, 256, 0, st>>>((const bf16*)x, n, out);
   NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" size_t nbest_wgrad_fp8_ws_bytes(int64_t M, int64_t N, int64_t K) {
+  int sp; int64_t kps;
+  plan8tt(M, N, K, &sp, &kps);
+  return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
+}
+
+// dW[M][N] (fp32, ldc) (+)= sum_k dY8[k][M-features] * X8[k][N-features] / s(a_amax); dY8 [K tokens][lda], X8 [K tokens][ldb] e4m3
+extern "C" int nbest_wgrad_fp8(const void* dY8, const void* X8, float* dW, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                               int64_t ldc, const uint32_t* a_amax, int accumulate, void* ws, size_t ws_bytes, nbest_stream_t stream) {
+  NB_CHECK(dY8 && X8 && dW && M > 0 && N > 0 && K > 0, NBEST_ERR_ARG, "wgrad_fp8: bad arguments");
+  NB_CHECK(M % 256 == 0 && N % 256 == 0, NBEST_ERR_SHAPE, "wgrad_fp8: output %lld x %lld must be multiples of 256", (long long)M, (long long)N);
+  NB_CHECK(lda % 16 == 0 && ldb % 16 == 0 && ldc % 8 == 0 && ((uintptr_t)dY8 & 15) == 0 && ((uintptr_t)X8 & 15) == 0 && ((uintptr_t)dW & 15) == 0,
+           NBEST_ERR_ALIGN, "wgrad_fp8: alignment");
+  GemmP8T p;
+  p.A = (const uint8_t*)dY8; p.B = (const uint8_t*)X8; p.C = dW; p.slab = (float*)ws;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  plan8tt(M, N, K, &p.splits, &p.k_per_split);
+  p.tiles_m = (int)(M / 256); p.tiles_n = (int)(N / 256);
+  p.accumulate = accumulate;
+  const int64_t ab = (K - 1) * lda + M, bb = (K - 1) * ldb + N;
+  NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "wgrad_fp8: operand larger than 4 GiB");
+  p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  p.a_amax = a_amax;
+  if (p.splits > 1) NB_CHECK(ws && ws_bytes >= (size_t)p.splits * M * N * sizeof(float), NBEST_ERR_WORKSPACE, "wgrad_fp8: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int lds_bytes = 4 * 2 * 256 * BK8;
+  (void)hipFuncSetAttribute((const void*)gemm8tt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  gemm8tt_kernel<<<p.tiles_m * p.tiles_n * p.splits, 512, lds_bytes, st>>>(p);
+  NB_LAUNCH_CHECK();
+  if (p.splits > 1) {
+    const int64_t MN = M * N;
+    int64_t g = (MN / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    splitk_reduce8_kernel<<<(int)g, 256, 0, st>>>(p.slab, dW, MN, N, ldc, p.splits, accumulate);
+    NB_LAUNCH_CHECK();
+  }
   return NBEST_OK;
 }
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
-    "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
+    "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_wgrad_fp8", "nbest_wgrad_fp8_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
 ]
 
 
@@ -120,6 +120,9 @@ def lib():
         L.nbest_transpose_weights.argtypes = [vp, vp, vp, i32, i32, vp]
         L.nbest_gemm_fp8.argtypes = [C.POINTER(GemmFp8Args), vp]
         L.nbest_cast_bf16_to_fp8.argtypes = [vp, vp, i64, vp]
+        L.nbest_wgrad_fp8_ws_bytes.restype = C.c_size_t
+        L.nbest_wgrad_fp8_ws_bytes.argtypes = [i64, i64, i64]
+        L.nbest_wgrad_fp8.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, i32, vp, sz, vp]
         L.nbest_quantize_weights_fp8.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
         L.nbest_gemm_fp8_ws_bytes.restype = C.c_size_t
         L.nbest_gemm_fp8_ws_bytes.argtypes = [C.POINTER(GemmFp8Args)]
@@ -245,6 +248,16 @@ def gemm_fp8(A8, W8, M, N, K, bias, out_scale=1.0, epilogue=EPI_BIAS, R=None, dr
         g.R, g.ldr = R.data_ptr(), R.stride(0)
     check(lib().nbest_gemm_fp8(C.byref(g), stream_ptr()), "gemm_fp8")
     return (out, U, C8) if epilogue == EPI_BIAS_GELU else out
+
+
+def wgrad_fp8(dY8, X8, M, N, K, a_amax=None, out=None, accumulate=False):
+    """dW[M,N] (fp32) = dY8^T . X8 over K token rows, both operands token-major e4m3 bytes"""
+    if out is None:
+        out = torch.zeros(M, N, dtype=torch.float32, device=dY8.device)
+    ws = _ws(lib().nbest_wgrad_fp8_ws_bytes(M, N, K), dY8.device)
+    check(lib().nbest_wgrad_fp8(ptr(dY8), ptr(X8), ptr(out), M, N, K, dY8.stride(0), X8.stride(0), out.stride(0), ptr(a_amax),
+                                int(accumulate), ptr(ws), ws.numel(), stream_ptr()), "wgrad_fp8")
+    return out
 
 
 def layernorm_fwd(x, gamma, beta, eps):

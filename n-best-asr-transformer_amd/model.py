@@ -66,6 +66,8 @@ class _Pass:
         d.off_emb_ln_b = a.by_name[pre + "LayerNorm.bias"].offset
         d.layers_host = C.cast(a.layer_offsets, C.POINTER(hb.LayerOffsets))
         d.drop_stream_base = stream_base
+        if model.fp8_forward:          # set before the stash is sized: the fp8 mode keeps e4m3 copies of the GEMM inputs per layer
+            d.w8, d.w8_inv_scale = a.w8.data_ptr(), a.w8_inv_scale.data_ptr()
         self.desc = d
         self.act_bytes = hb.lib().nbest_encoder_act_bytes(C.byref(d))
         self.act = None                    # a view of the slot's grow-only stash, bound by NBestSTCModel._pass

@@ -108,31 +108,34 @@ def _fp8_scale(t):
 
 class _Fp8Linear(torch.autograd.Function):
     """"fp8w" GEMMs of one nn.Linear.  Forward: y = e4m3(x) . e4m3(W * s_w)^T / s_w + b (per-matrix scale s_w,
-    nbest_quantize_weights_fp8; unit-scale activations).  Backward: the weight gradient is the bf16 path's (bf16 gradient x
-    bf16 activation -> fp32); the input gradient is, with ``bwd8``, the fp8 dgrad e4m3(g * s_g) / s_g . e4m3(W * s_w) / s_w with
+    nbest_quantize_weights_fp8; unit-scale activations).  Backward without ``bwd8``: the bf16 path's (bf16 gradient x bf16 activation
+    -> fp32 weight gradient, bf16 dgrad on the bf16 weight copy).  With ``bwd8`` both are fp8: g8 = e4m3(g * s_g) / s_g feeds the
+    dgrad g8 . e4m3(W * s_w) / s_w and the weight gradient g8^T . e4m3(x) (the forward's own e4m3 copy of the input), with
     the per-tensor gradient scale s_g (the HIP path takes it from the previous pass's amax of the same tensor; the parity test
-    runs the same batch twice, so that is this tensor's own amax), else the bf16 dgrad on the bf16 weight copy."""
+    runs the same batch twice, so that is this tensor's own amax)."""
 
     @staticmethod
     def forward(ctx, x, w, b, bwd8, x_is_f32):
         s = _fp8_scale(w)
         w8 = _e4m3(w * s) / s
-        ctx.save_for_backward(_r(x) if x_is_f32 else x, w8 if bwd8 else _r(w))
+        ctx.save_for_backward(_e4m3(x) if bwd8 else _r(x) if x_is_f32 else x, w8 if bwd8 else _r(w))
         ctx.bwd8, ctx.round_dx = bwd8, x_is_f32
         return F.linear(_e4m3(x), w8) + b
 
     @staticmethod
     def backward(ctx, g):
-        x16, wd = ctx.saved_tensors
+        xs, wd = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
+        gw = g2
         if ctx.bwd8:
             sg = _fp8_scale(g2)
-            dx = (_e4m3(g * sg) / sg) @ wd
+            gw = _e4m3(g2 * sg) / sg
+            dx = gw.view_as(g) @ wd
         else:
             dx = g @ wd
         if ctx.round_dx:
             dx = _r(dx)
-        return dx, g2.t() @ x16.reshape(-1, x16.shape[-1]), g2.sum(0), None, None
+        return dx, gw.t() @ xs.reshape(-1, xs.shape[-1]), g2.sum(0), None, None
 
 
 class _GeluStoreFp8(torch.autograd.Function):

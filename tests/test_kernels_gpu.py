@@ -411,3 +411,20 @@ def test_gemm_fp8_forward_epilogues(M, N, K):
           ref + R.float(), 1e-2)
     x = rnd(M, K, dtype=torch.bfloat16, seed=9)
     assert torch.equal(hb.cast_fp8(x).view(torch.float8_e4m3fn).float(), _e4m3(x.float().cpu()).float().to(DEV))     # RNE, like torch
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (768, 768, 1000), (2304, 768, 4096), (768, 3072, 5000)])
+def test_wgrad_fp8_transposed_reads(M, N, K):
+    """fp8 weight gradient dW = dY8^T . X8 over K token rows (ragged K: zero-filled tail), both operands token-major e4m3 read
+    through ds_read_b64_tr_b8: every product is exact in fp32, so the result matches the fp32 matmul of the dequantised operands
+    up to the accumulation inside the block-scaled MFMA (measured 1.4e-5 .. 3.1e-5 of the largest entry - the instruction's
+    internal sum of 64 products is not a full fp32 chain); split-K + accumulate; gradient scale taken from device float bits"""
+    g = torch.Generator().manual_seed(M + N + K)
+    dY8 = _e4m3(torch.randn(K, M, generator=g)).to(DEV)
+    X8 = _e4m3(torch.randn(K, N, generator=g)).to(DEV)
+    ref = dY8.float().t() @ X8.float()
+    got = hb.wgrad_fp8(dY8.view(torch.uint8), X8.view(torch.uint8), M, N, K)
+    close("wgrad_fp8[%dx%d K=%d]" % (M, N, K), got, ref, 1e-4)
+    amax = torch.tensor([3.0], device=DEV).view(torch.int32)             # scale 2^floor(log2(224/3)) = 64
+    got2 = hb.wgrad_fp8(dY8.view(torch.uint8), X8.view(torch.uint8), M, N, K, a_amax=amax, out=got.clone(), accumulate=True)
+    close("wgrad_fp8 scaled + accumulate", got2, ref * (1 + 1 / 64.0), 1e-4)

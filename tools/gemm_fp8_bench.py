@@ -24,3 +24,17 @@ for nm, N, K, epi in (("qkv", 3 * H, H, hb.EPI_BIAS), ("attn_out", H, H, hb.EPI_
     t16 = timeit(lambda: hb.gemm(A, W, M, N, K, epilogue=epi, bias=bias, out=out, U=U if epi == hb.EPI_BIAS_GELU else None, **kw))
     t8 = timeit(lambda: hb.gemm_fp8(A8, W8, M, N, K, bias, 1.0, epilogue=epi, out=out, **kw))
     print("%-9s N=%4d K=%4d epi %d   bf16 %7.1f us %6.0f TF/s | fp8 %7.1f us %6.0f TF/s  (x%.2f)" % (nm, N, K, epi, t16 * 1e3, fl / t16 / 1e9, t8 * 1e3, fl / t8 / 1e9, t16 / t8), flush=True)
+
+# weight gradients: bf16 TT kernel vs fp8 transposed-read kernel (K = M tokens)
+for nm, Mo, No in (("qkv", 3 * H, H), ("attn_out", H, H), ("ffn_up", F, H), ("ffn_down", H, F)):
+    dY, X = r(M, Mo).bfloat16(), r(M, No).bfloat16()
+    dY8, X8 = dY.float().to(torch.float8_e4m3fn).view(torch.uint8), X.float().to(torch.float8_e4m3fn).view(torch.uint8)
+    o32 = torch.empty(Mo, No, dtype=torch.float32, device=dev)
+    fl = 2.0 * M * Mo * No
+    t16 = timeit(lambda: hb.gemm(dY, X, Mo, No, M, 1, 1, hb.EPI_F32_SPLITK, out=o32))
+    import ctypes as C
+    ws = torch.empty(max(hb.lib().nbest_wgrad_fp8_ws_bytes(Mo, No, M), 16), dtype=torch.uint8, device=dev)
+    def f8():
+        hb.check(hb.lib().nbest_wgrad_fp8(hb.ptr(dY8), hb.ptr(X8), hb.ptr(o32), Mo, No, M, Mo, No, No, None, 0, hb.ptr(ws), ws.numel(), hb.stream_ptr()), "wgrad_fp8")
+    t8 = timeit(f8)
+    print("wgrad %-9s %4dx%4d K=%d   bf16 %7.1f us %6.0f TF/s | fp8 %7.1f us %6.0f TF/s  (x%.2f)" % (nm, Mo, No, M, t16 * 1e3, fl / t16 / 1e9, t8 * 1e3, fl / t8 / 1e9, t16 / t8), flush=True)
