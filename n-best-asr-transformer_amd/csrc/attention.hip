@@ -190,7 +190,7 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
     const int p = i * 64 + lane, row = p >> 3, ch = p & 7;
     if (row < rows_valid) {
       const i32x4 v = *(const i32x4*)(img + (row0 + row) * 128 + ch * 16);
-      *(i32x4*)(gbase + (int64_t)row * gld + ch * 8) = v;
+      if (gbase) *(i32x4*)(gbase + (int64_t)row * gld + ch * 8) = v;   // (null: only the e4m3 copy is wanted)
       if (g8 || amax) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, v);
         float f[8];
@@ -630,14 +630,14 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
   if (wave < NKB) {
     const int r0 = 32 * wave;      // wave w holds dQ of query block w (w = qb mod NW, NKB <= NW) and dK/dV of key block w
     const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
-    bf16* g = dqkv + goff;
+    bf16* g = dqkv ? dqkv + goff : nullptr;
     uint8_t* g8 = f8.out8 ? f8.out8 + goff : nullptr;
     const float s8 = fp8_grad_scale(f8.amax_prev);
     float amax8 = 0.f;
     float* am = f8.amax_new ? &amax8 : nullptr;
     store_tile(Qt, r0, dq0, dq1, lane, g, ld, S - r0, g8, s8, am);
-    store_tile(Kt, r0, dk0, dk1, lane, g + H, ld, S - r0, g8 ? g8 + H : nullptr, s8, am);
-    store_tile(dOt, r0, dv0, dv1, lane, g + 2 * H, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, am);
+    store_tile(Kt, r0, dk0, dk1, lane, g ? g + H : nullptr, ld, S - r0, g8 ? g8 + H : nullptr, s8, am);
+    store_tile(dOt, r0, dv0, dv1, lane, g ? g + 2 * H : nullptr, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, am);
     if (f8.amax_new) {
       amax8 = wave_max(amax8);
       if (lane == 0) amax_update(f8.amax_new, amax8);
@@ -922,10 +922,10 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
       for (int r = 0; r < 16; ++r) { ck0 += dk0[r]; ck1 += dk1[r]; cv0 += dv0[r]; cv1 += dv1[r]; }
       const int r0 = key0 + 32 * wave;
       const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
-      bf16* g = dqkv + goff;
+      bf16* g = dqkv ? dqkv + goff : nullptr;
       uint8_t* g8 = f8.out8 ? f8.out8 + goff : nullptr;
-      store_tile(Kt + wave * 4096, 0, dk0, dk1, lane, g + H, ld, S - r0, g8 ? g8 + H : nullptr, s8, am);
-      store_tile(Kt + wave * 4096, 0, dv0, dv1, lane, g + 2 * H, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, am);
+      store_tile(Kt + wave * 4096, 0, dk0, dk1, lane, g ? g + H : nullptr, ld, S - r0, g8 ? g8 + H : nullptr, s8, am);
+      store_tile(Kt + wave * 4096, 0, dv0, dv1, lane, g ? g + 2 * H : nullptr, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, am);
     }
   }
   __syncthreads();
@@ -954,12 +954,12 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
   if (wave < nkb) {
     const int r0 = 32 * wave;
     const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
-    store_tile(Kt + wave * 4096, 0, dqa0, dqa1, lane, dqkv + goff, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, am);
+    store_tile(Kt + wave * 4096, 0, dqa0, dqa1, lane, dqkv ? dqkv + goff : nullptr, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, am);
   }
   if (wave + 8 < nkb) {
     const int r0 = 32 * (wave + 8);
     const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
-    store_tile(Kt + wave * 4096, 0, dqb0, dqb1, lane, dqkv + goff, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, am);
+    store_tile(Kt + wave * 4096, 0, dqb0, dqb1, lane, dqkv ? dqkv + goff : nullptr, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, am);
   }
   if (f8.amax_new) {
     amax8 = wave_max(amax8);
@@ -1059,7 +1059,7 @@ extern "C" size_t nbest_attention_bwd_ws_bytes(int B, int S, int heads) {
 int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
                                   void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, Fp8Grad f8) {
-  NB_CHECK(qkv && key_mask && ctx && dctx && lse && dqkv, NBEST_ERR_ARG, "attention_bwd: null pointer");
+  NB_CHECK(qkv && key_mask && ctx && dctx && lse && (dqkv || (f8.out8 && dtype == NBEST_BF16)), NBEST_ERR_ARG, "attention_bwd: null pointer");
   if (int e = check_common("attention_bwd", B, S, heads, d, dtype)) return e;
   NB_CHECK(!dbias || (ws && ws_bytes >= nbest_attention_bwd_ws_bytes(B, S, heads)), NBEST_ERR_WORKSPACE,
            "attention_bwd: bias-gradient workspace too small");

@@ -125,6 +125,12 @@ static WsLayout ws_layout(const nbest_encoder_desc* d) {
   return w;
 }
 
+// the backward of this pass runs its dgrad / wgrad GEMMs in fp8 (same answer in the forward, which then leaves out the
+// bf16 tensors only a bf16 backward would read, and in the backward)
+static bool fp8_backward_active(const nbest_encoder_desc* d) {
+  return d->dtype == NBEST_BF16 && d->w8 && d->fp8_bwd && d->w8t && d->w8_inv_scale && d->gamax_prev && d->gamax_new;
+}
+
 static int check_desc(const nbest_encoder_desc* d) {
   NB_CHECK(d && d->layers_host, NBEST_ERR_ARG, "encoder: null descriptor");
   NB_CHECK(d->dtype == NBEST_F32 || d->dtype == NBEST_BF16, NBEST_ERR_DTYPE, "encoder: bad dtype %d", d->dtype);
@@ -232,7 +238,8 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     RUN(nbest_internal_layernorm_fwd8(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, x18, st1, M, H, d->ln_eps, dt, stream));
     // FFN up + bias + GELU (GELU' of the pre-activation kept for the backward)
     if (f8) {
-      RUN(gemm8(x18, o.w1, 4 * l + 2, hact, F, H, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, u, h8, 0.f, 0));
+      // (bf16 gelu(u) has one reader, the bf16 FFN-down weight gradient: not written when the backward runs in fp8)
+      RUN(gemm8(x18, o.w1, 4 * l + 2, fp8_backward_active(d) ? nullptr : hact, F, H, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, u, h8, 0.f, 0));
     } else
     RUN(gemm(dt, x1, P.W(o.w1), hact, M, F, H, H, H, F, 0, 0, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, 0, u, F, nullptr, 0, 0, 0.f,
              0, 0, st));
@@ -289,7 +296,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   // fp8 dgrads (descriptor: w8t, gamax_prev / gamax_new, fp8_bwd): the gradient amax of every dgrad operand is recorded in
   // every pass; with a history (fp8_bwd) the producers also write e4m3 copies and the four dgrad GEMMs of a layer run in fp8
   const bool rec = d->gamax_new && dt == NBEST_BF16;
-  const bool f8b = rec && d->fp8_bwd && d->w8t && d->w8_inv_scale && d->gamax_prev;
+  const bool f8b = fp8_backward_active(d);
   uint8_t* dqkv8 = f8b ? (uint8_t*)W + w.f8 : nullptr;                       // [M][3H]
   uint8_t* dBig8 = f8b ? dqkv8 + 3 * al((size_t)M * H) : nullptr;            // [M][F]
   uint8_t* dRd8 = f8b ? dBig8 + al((size_t)M * F) : nullptr;                 // [M][H]
@@ -318,12 +325,13 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     const uint8_t* x8 = (const uint8_t*)(Lb + a.o_x8); const uint8_t* ctx8 = (const uint8_t*)(Lb + a.o_ctx8);
     const uint8_t* x18 = (const uint8_t*)(Lb + a.o_x18); const uint8_t* h8 = (const uint8_t*)(Lb + a.o_h8);
     // LN2 backward: dR (residual branch), dRd (dense branch, under the dropout mask), db2
-    RUN(nbest_internal_layernorm_bwd8(dA, r2, st2, P.P(o.ln2_g), dR, hdrop ? dRd : nullptr, G(o.ln2_g), G(o.ln2_b), G(o.b2), M, H, dt,
+    // (with fp8 dgrads / wgrads the bf16 forms of dRd, dBig and dqkv have no reader: only their e4m3 copies are written)
+    RUN(nbest_internal_layernorm_bwd8(dA, r2, st2, P.P(o.ln2_g), dR, (hdrop && !f8b) ? dRd : nullptr, G(o.ln2_g), G(o.ln2_b), G(o.b2), M, H, dt,
                                       accumulate, d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream, fg(dRd8, 4 * l + 0)));
     // FFN-down: dgrad fused with GELU' -> dU ; wgrad
     // (the FFN-up bias gradient = column sums of dU is fused into this epilogue)
     if (f8b) {
-      RUN(dgrad8(dRd8, 4 * l + 0, o.w2, 4 * l + 3, dBig, F, H, NBEST_EPI_DGELU, nullptr, u, dBig8, 4 * l + 1, G(o.b1)));
+      RUN(dgrad8(dRd8, 4 * l + 0, o.w2, 4 * l + 3, nullptr, F, H, NBEST_EPI_DGELU, nullptr, u, dBig8, 4 * l + 1, G(o.b1)));
     } else {
       RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red, w.red_bytes, accumulate,
                0.f, 0, 0, st, G(o.b1)));
@@ -343,7 +351,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
                   accumulate, 0.f, 0, 0, st));
     stamp(1);
     // LN1 backward
-    RUN(nbest_internal_layernorm_bwd8(dB1, r1, st1, P.P(o.ln1_g), dR, hdrop ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt,
+    RUN(nbest_internal_layernorm_bwd8(dB1, r1, st1, P.P(o.ln1_g), dR, (hdrop && !f8b) ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt,
                                       accumulate, d->hidden_drop, d->seed, s0 + 1, red, w.red_bytes, stream, fg(dRd8, 4 * l + 2)));
     // attention output projection: dgrad ; wgrad
     if (f8b) RUN(dgrad8(dRd8, 4 * l + 2, o.wo, 4 * l + 1, dctx, H, H, NBEST_EPI_NONE, nullptr, nullptr, nullptr, -1, nullptr));
@@ -354,7 +362,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
                   accumulate, 0.f, 0, 0, st));
     stamp(1);
     // attention backward -> dqkv ; QKV bias gradient
-    RUN(nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64,
+    RUN(nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, f8b ? nullptr : dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64,
                                       dt, d->attn_drop, d->seed, s0 + 0, stream, fg(dqkv8, 4 * l + 3)));
     // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
     if (f8b) RUN(dgrad8(dqkv8, 4 * l + 3, o.wqkv, 4 * l + 0, dA, H, 3 * H, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));

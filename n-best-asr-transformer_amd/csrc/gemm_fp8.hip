@@ -9,7 +9,9 @@
 // two-group slot schedule are unchanged; a stage now feeds 8 MFMAs of K = 64 per wave instead of 32 of K = 32.
 //   fragment: lane l holds row (l & 31) of a 32-row block and the 32 bytes [32 g, 32 g + 32) of its 64-byte k-row,
 //             g = l >> 5 (any k order works as long as A and B use the same one - checked by tools/micro/mx_probe.py);
-//   LDS image [rows][64 B]: 16-byte chunk index ^= (row >> 1) & 3 (conflict-free for 8 consecutive rows of one chunk);
+//   LDS image [rows][64 B]: 16-byte chunk index ^= (row >> 2) & 3 - conflict-free for ds_read_b128's four 16-lane groups
+//             ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32): rows of one class r % 4 share 4 of the 16 slots
+//             of the bank row, and within a group their r >> 2 are {0,3,5,6} or {1,2,4,7}: distinct in the low two bits;
 //   C/D: with the operands swapped (B first) lane l owns output row (l & 31) and the columns
 //        (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the 32-column block: four groups of 4 consecutive columns.
 // Epilogues: NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU (writes gelu bf16, gelu' 8-bit AND the fp8 copy of gelu the next GEMM
@@ -20,6 +22,13 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 constexpr int BK8 = 64;
+#ifndef NBEST_DIAG
+#define NBEST_DIAG 0
+#endif
+// timing-only ablations of the epilogue (`make diag DIAG=<mask>`, results are wrong): 256 no GELU math, 512 no 8-bit stores,
+// 1024 no bf16 store, 2048 no main loop, 4096 nontemporal stores; of the ping-pong main loop: 1 no in-loop DMA, 2 no fragment
+// reads, 4 no MFMA
+constexpr int DIAG8 = NBEST_DIAG;
 
 struct GemmP8 {
   const uint8_t* A; const uint8_t* B; bf16* C; const float* bias; const bf16* R; uint8_t* U; uint8_t* C8;
@@ -32,28 +41,37 @@ struct GemmP8 {
   Fp8Grad c8g;                 // DGELU: e4m3 copy of the output gradient (scaled by ITS previous amax) + its new amax
   float* colpart;              // DGELU: fused column sums of the output (bias gradient), partial rows [tiles_m * 2][N]
   DropCfg drop;
+  int stagger_10ns;            // WN = 2: start delay of every second first-round workgroup of a CU (units of the 100 MHz clock)
 };
+
+// Arrival counters per CU (key: XCC | SE | SH | CU of HW_ID), never reset: only the PARITY of a workgroup's arrival number
+// is used, and the two workgroups that share a CU in the first round of a launch draw consecutive numbers.
+__device__ unsigned g_cu_arrivals[2048];
+#ifdef NBEST_EXPERIMENTS
+__device__ unsigned long long* g_trace8;   // per workgroup: key | late << 16, t_start, t_main_end, t_end (100 MHz clock)
+#endif
 
 __device__ __forceinline__ int xcd_remap8(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// one operand tile: 256 rows x 64 bytes = 1024 16-byte chunks, 512 threads -> 2 LDS-DMA instructions per thread
+// one operand tile: ROWS rows x 64 bytes = 4 ROWS 16-byte chunks, NT threads -> 4 ROWS / NT LDS-DMA instructions per thread
+template <int ROWS = 256, int NT = 512>
 __device__ __forceinline__ void stage_tile8(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid) {
   const int wave = tid >> 6;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int p = i * 512 + tid;
+  for (int i = 0; i < ROWS * 4 / NT; ++i) {
+    const int p = i * NT + tid;
     const int row = p >> 2, slot = p & 3;
-    const int kc = slot ^ ((row >> 1) & 3);
+    const int kc = slot ^ ((row >> 2) & 3);
     const uint32_t voff = (uint32_t)((row0 + row) * ld + k0 + kc * 16);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * 512 + wave * 64) * 16), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, voff, 0, 0, 0);
   }
 }
 
 __device__ __forceinline__ i32x8 read_frag8(const char* tile, int row_base, int lane) {
-  const int row = row_base + (lane & 31), g = lane >> 5, sw = (row >> 1) & 3;
+  const int row = row_base + (lane & 31), g = lane >> 5, sw = (row >> 2) & 3;
   const i32x4 lo = *(const i32x4*)(tile + row * 64 + (((2 * g) ^ sw) << 4));
   const i32x4 hi = *(const i32x4*)(tile + row * 64 + (((2 * g + 1) ^ sw) << 4));
   return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -61,19 +79,24 @@ __device__ __forceinline__ i32x8 read_frag8(const char* tile, int row_base, int 
 
 template <int N> __device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
+// WN = 4: 256x256 tile, 8 waves, ONE workgroup per CU (4-stage ring = 128 KiB), the two wave groups ping-pong.
+// WN = 2: 256x128 tile, 4 waves, TWO workgroups per CU (3-stage ring = 72 KiB each, <= 256 registers): no choreography
+//         between them - while one workgroup is in its (VALU-bound: GELU, fp8 packing) epilogue the other one's main loop owns
+//         the matrix pipe.  Pays 1.5x the LDS-DMA bytes per flop; chosen for the shapes whose epilogue is as long as their
+//         main loop (K = 768).
+template <int EPI, int WN>
+__global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int BM = 256, BN = 256, WN = 4, NT = 512, STAGES = 4;
+  constexpr int BM = 256, BN = 64 * WN, NT = 128 * WN, STAGES = (WN == 4) ? 4 : 3;
   constexpr int WTM = 128, WTN = 64, TMb = 4, TNb = 2;              // 32x32 blocks per wave tile
-  constexpr int A_BYTES = BM * BK8, STAGE = 2 * A_BYTES;            // 16 KiB + 16 KiB
-  constexpr int NDMA = 4;                                           // LDS-DMA instructions per thread and stage
+  constexpr int A_BYTES = BM * BK8, STAGE = A_BYTES + BN * BK8;     // 16 KiB + 16 (8) KiB
+  constexpr int NDMA = (BM + BN) * 4 / NT;                          // LDS-DMA instructions per thread and stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int id = xcd_remap8(blockIdx.x, gridDim.x);
   const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-  const int nk = (int)(p.K / BK8);
+  const int nk = (DIAG8 & 2048) ? 1 : (int)(p.K / BK8);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
 
@@ -110,63 +133,132 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- ping-pong main loop (see gemm_bf16_v2.hip: the two waves of every SIMD run one slot out of phase) ----
-  const int grp = __builtin_amdgcn_readfirstlane(wm);
-#pragma unroll
-  for (int s0 = 0; s0 < STAGES - 1; ++s0) {
-    if (s0 < nk) {
-      stage_tile8(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
-      stage_tile8(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
-    }
-  }
-  {
-    const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
-    if (younger >= 2) wait_vm8<2 * NDMA>();
-    else if (younger == 1) wait_vm8<NDMA>();
-    else wait_vm8<0>();
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (grp == 1) __builtin_amdgcn_s_barrier();
-  int buf = 0;
   i32x8 af[TMb], bfr[TNb];
-  for (int kt = 0; kt < nk; ++kt) {
-    // ---------------- LOAD slot ----------------
-    if (kt + STAGES - 1 < nk) {
-      int nb = buf + STAGES - 1;
-      if (nb >= STAGES) nb -= STAGES;
-      const int64_t k0 = (int64_t)(kt + STAGES - 1) * BK8;
-      stage_tile8(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-      stage_tile8(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+  if constexpr (WN == 4) {
+    // ---- ping-pong main loop (see gemm_bf16_v2.hip: the two waves of every SIMD run one slot out of phase) ----
+    const int grp = __builtin_amdgcn_readfirstlane(wm);
+  #pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0) {
+      if (s0 < nk) {
+        stage_tile8<BM, NT>(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
+        stage_tile8<BN, NT>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
+      }
     }
-    const char* cur = lds + buf * STAGE;
-#pragma unroll
-    for (int j = 0; j < TNb; ++j) bfr[j] = read_frag8(cur + A_BYTES, wn * WTN + j * 32, lane);
-#pragma unroll
-    for (int i = 0; i < TMb; ++i) af[i] = read_frag8(cur, wm * WTM + i * 32, lane);
     {
-      const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1;   // stages kt+1.. outstanding
-      if (c >= 3) wait_vm8<2 * NDMA>();
-      else if (c == 2) wait_vm8<NDMA>();
-      else if (c == 1) wait_vm8<0>();
+      const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
+      if (younger >= 2) wait_vm8<2 * NDMA>();
+      else if (younger == 1) wait_vm8<NDMA>();
+      else wait_vm8<0>();
     }
-    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---------------- MFMA slot ----------------
-    __builtin_amdgcn_s_setprio(1);
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---------------- LOAD slot ----------------
+      if (!(DIAG8 & 1) && kt + STAGES - 1 < nk) {
+        int nb = buf + STAGES - 1;
+        if (nb >= STAGES) nb -= STAGES;
+        const int64_t k0 = (int64_t)(kt + STAGES - 1) * BK8;
+        stage_tile8<BM, NT>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+        stage_tile8<BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+      }
+      const char* cur = lds + buf * STAGE;
+  #pragma unroll
+      for (int j = 0; j < TNb; ++j) if (!(DIAG8 & 2) || kt == 0) bfr[j] = read_frag8(cur + A_BYTES, wn * WTN + j * 32, lane);
+  #pragma unroll
+      for (int i = 0; i < TMb; ++i) if (!(DIAG8 & 2) || kt == 0) af[i] = read_frag8(cur, wm * WTM + i * 32, lane);
+      {
+        const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1;   // stages kt+1.. outstanding
+        if (c >= 3) wait_vm8<2 * NDMA>();
+        else if (c == 2) wait_vm8<NDMA>();
+        else if (c == 1) wait_vm8<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- MFMA slot ----------------
+      __builtin_amdgcn_s_setprio(1);
+  #pragma unroll
+      for (int i = 0; i < TMb; ++i)
+  #pragma unroll
+        for (int j = 0; j < TNb; ++j)
+          if (!(DIAG8 & 4) || kt == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 127, 0, 127);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
+    // ---- two independent workgroups per CU: plain 3-stage ring, one barrier per k-step ----
+    // Left alone, the two workgroups of a CU start together and stay in phase: both in the main loop (sharing the matrix
+    // pipe), then both in the epilogue (sharing VALU and the store path) - nothing overlaps.  One of the two therefore
+    // starts late by about one main loop; later rounds inherit the offset (a workgroup starts when its predecessor ends).
+#ifdef NBEST_EXPERIMENTS
+    if (g_trace8 && tid == 0) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_trace8[blockIdx.x * 4 + 0] = ((unsigned long long)xcc << 32) | hw;
+      g_trace8[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    if (p.stagger_10ns > 0 && blockIdx.x < 512) {
+      int late = 0;
+      if (tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned key = ((xcc & 7) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+        late = atomicAdd(&g_cu_arrivals[key], 1u) & 1;
+      }
+      late = __builtin_amdgcn_readfirstlane(late);
+      if (wave == 0 && late) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) < p.stagger_10ns) __builtin_amdgcn_s_sleep(32);
+      }
+      __builtin_amdgcn_s_barrier();
+    }
 #pragma unroll
-    for (int i = 0; i < TMb; ++i)
+    for (int s0 = 0; s0 < STAGES - 1; ++s0) {
+      if (s0 < nk) {
+        stage_tile8<BM, NT>(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
+        stage_tile8<BN, NT>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
+      }
+    }
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_vm8<NDMA>();       // stage kt landed (stage kt + 1 may still be in flight)
+      else wait_vm8<0>();
+      __builtin_amdgcn_s_barrier();            // ... for every wave; and every wave is done reading stage kt - 1
+      asm volatile("" ::: "memory");
+      if (kt + STAGES - 1 < nk) {
+        int nb = buf + STAGES - 1;
+        if (nb >= STAGES) nb -= STAGES;
+        const int64_t k0 = (int64_t)(kt + STAGES - 1) * BK8;
+        stage_tile8<BM, NT>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+        stage_tile8<BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+      }
+      const char* cur = lds + buf * STAGE;
 #pragma unroll
-      for (int j = 0; j < TNb; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 127, 0, 127);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+      for (int j = 0; j < TNb; ++j) bfr[j] = read_frag8(cur + A_BYTES, wn * WTN + j * 32, lane);
+#pragma unroll
+      for (int i = 0; i < TMb; ++i) af[i] = read_frag8(cur, wm * WTM + i * 32, lane);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TMb; ++i)
+#pragma unroll
+        for (int j = 0; j < TNb; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 127, 0, 127);
+      __builtin_amdgcn_s_setprio(0);
+      buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    }
+#ifdef NBEST_EXPERIMENTS
+    if (g_trace8 && tid == 0) g_trace8[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: 32-row blocks restaged through wave-private LDS ([32][64] fp32, chunk16 ^= row & 15) ----
   float* ep = (float*)lds + wave * 2048;
@@ -206,12 +298,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float cdf, ex;
+          if (DIAG8 & 256) { gp[e] = v[e]; continue; }
           gelu_parts_fast(v[e], cdf, ex);
           gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);
           v[e] *= cdf;
         }
+        if (DIAG8 & 4096) {
+          __builtin_nontemporal_store(i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, (i32x2*)(p.U + m * p.ldu + en8));
+          __builtin_nontemporal_store(i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)}, (i32x2*)(p.C8 + m * p.ldc8 + en8));
+        } else if (!(DIAG8 & 512)) {
         *(i32x2*)(p.U + m * p.ldu + en8) = i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)};
         *(i32x2*)(p.C8 + m * p.ldc8 + en8) = i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)};
+        } else if (gp[0] + gp[3] + gp[5] == 123.f) p.U[0] = 1;
       }
       if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
         const uint32_t base = (uint32_t)(m * p.N + en8);
@@ -241,7 +339,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
           }
         }
       }
-      Vec8<bf16>::store(p.C + m * p.ldc + en8, v);
+      if ((EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_DGELU) && !p.C) continue;   // only the e4m3 copy is wanted
+      if (DIAG8 & 4096) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        __builtin_nontemporal_store(o, (bf16x8*)(p.C + m * p.ldc + en8));
+      } else if (!(DIAG8 & 1024)) Vec8<bf16>::store(p.C + m * p.ldc + en8, v);
+      else if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 123.f) p.C[0] = (bf16)1.f;
     }
     asm volatile("" ::: "memory");
   }
@@ -262,6 +367,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmP8 p) {
     amax8 = wave_max(amax8);
     if (lane == 0) amax_update(p.c8g.amax_new, amax8);
   }
+#ifdef NBEST_EXPERIMENTS
+  if (WN == 2 && g_trace8 && tid == 0) g_trace8[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // bf16 [n] -> e4m3 (unit scale): the A operands of the fp8 forward GEMMs that no producer kernel writes directly
@@ -348,7 +456,9 @@ __global__ __launch_bounds__(256) void quant_w8t_kernel(const float* __restrict_
 // in a 16-lane group, lane i receives byte (i & 7) of the 8-byte chunks addressed by lanes 2j + (i >> 3), j = 0..7 - an 8x8 byte
 // transpose per lane parity.  With source lane (j, p) of group G pointing at token row 32 (G >> 1) + 8 q + j, feature chunk
 // 16 (G & 1) + 8 p, read q = 0..3 gives lane l tokens 32 (l >> 5) + 8 q .. + 7 of feature (l & 31): the MX operand.
-// LDS image [64 tokens][256 B]: 16-byte chunk index ^= token & 7 (the 8 rows of a transposed read hit 8 different chunks).
+// LDS image [64 tokens][256 B]: 16-byte chunk c of a token row sits in slot ((c & 1) << 3 | c >> 1) ^ (token & 7): the 8 rows
+// of a transposed read hit 8 different slots, and the two 16-lane groups of a 32-lane half (chunks c, c + 1) opposite
+// 128-byte halves of the bank row - conflict-free (with c ^ (token & 7) they met on the same half: 2-way).
 // Same ping-pong schedule and 4-stage ring as gemm8_kernel (a stage = 64 tokens x 256 features per operand = 16 KiB);
 // split-K over tokens into fp32 slabs, reduced by the caller (nbest_internal_splitk_reduce).
 struct GemmP8T {
@@ -366,7 +476,8 @@ __device__ __forceinline__ void stage_tile8t(__amdgpu_buffer_rsrc_t rs, char* ti
   for (int i = 0; i < 2; ++i) {
     const int p = i * 512 + tid;                 // 64 token rows x 16 chunks of 16 bytes
     const int row = p >> 4, slot = p & 15;
-    const int c = slot ^ (row & 7);
+    const int t = slot ^ (row & 7);
+    const int c = ((t & 7) << 1) | (t >> 3);     // slot = (chunk parity << 3 | chunk >> 1) ^ (token & 7)
     const uint32_t voff = (uint32_t)((k0 + row) * ld + f0 + c * 16);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * 512 + wave * 64) * 16), 16, voff, 0, 0, 0);
   }
@@ -387,7 +498,7 @@ __device__ __forceinline__ i32x8 read_frag8t(const char* tile, int f0, int lane)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = 32 * (G >> 1) + 8 * q + j;
-    const i32x2 v = ds_read_tr8_asm(tile + row * 256 + ((chunk ^ (row & 7)) << 4) + 8 * pp);
+    const i32x2 v = ds_read_tr8_asm(tile + row * 256 + (((((chunk & 1) << 3) | (chunk >> 1)) ^ (row & 7)) << 4) + 8 * pp);
     out[2 * q] = v[0]; out[2 * q + 1] = v[1];
   }
   return out;
@@ -634,12 +745,20 @@ extern "C" int nbest_quantize_weights_fp8(const float* master, void* w8, void* w
 
 int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
 
+#ifdef NBEST_EXPERIMENTS
+extern "C" int nbest_experiment_trace8(void* buf) {   // nullptr: off
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace8), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" size_t nbest_gemm_fp8_ws_bytes(const nbest_gemm_fp8_args* a) {
   return (a && a->colsum_out) ? (size_t)((a->M + 255) / 256) * 2 * a->N * sizeof(float) : 0;
 }
 
 extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream) {
-  NB_CHECK(a && a->A && a->B && a->C, NBEST_ERR_ARG, "gemm_fp8: null pointer");
+  NB_CHECK(a && a->A && a->B, NBEST_ERR_ARG, "gemm_fp8: null pointer");
+  // the bf16 output may be dropped where the epilogue also writes the e4m3 copy its only readers take
+  NB_CHECK(a->C || ((a->epilogue == NBEST_EPI_BIAS_GELU || a->epilogue == NBEST_EPI_DGELU) && a->C8), NBEST_ERR_ARG, "gemm_fp8: null output");
   NB_CHECK(a->M > 0 && a->N % 256 == 0 && a->K % BK8 == 0 && a->K >= BK8, NBEST_ERR_SHAPE,
            "gemm_fp8: needs N %% 256 == 0 and K %% 64 == 0 (M=%lld N=%lld K=%lld)", (long long)a->M, (long long)a->N, (long long)a->K);
   NB_CHECK(a->lda % 16 == 0 && a->ldb % 16 == 0 && a->ldc % 8 == 0, NBEST_ERR_ALIGN, "gemm_fp8: leading dimensions");
@@ -664,8 +783,13 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
   p.A = (const uint8_t*)a->A; p.B = (const uint8_t*)a->B; p.C = (bf16*)a->C; p.bias = a->bias; p.R = (const bf16*)a->R;
   p.U = (uint8_t*)a->U; p.C8 = (uint8_t*)a->C8;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldu = a->ldu; p.ldc8 = a->ldc8;
+  // two small workgroups per CU where the epilogue weighs as much as the main loop (short K), one big one elsewhere
+  int wn = (a->K <= 1024 && (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU)) ? 2 : 4;
+#ifdef NBEST_EXPERIMENTS
+  if (const char* e = getenv("NBEST_GEMM8_WN")) if (e[0] == '2' || e[0] == '4') wn = e[0] - '0';
+#endif
   p.tiles_m = (int)((a->M + 255) / 256);
-  p.tiles_n = (int)(a->N / 256);
+  p.tiles_n = (int)(a->N / (64 * wn));
   const int64_t ab = (a->M - 1) * a->lda + a->K, bb = (a->N - 1) * a->ldb + a->K;
   NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm_fp8: operand larger than 4 GiB");
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
@@ -676,13 +800,22 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
   p.colpart = (epi == NBEST_EPI_DGELU && a->colsum_out) ? (float*)a->ws : nullptr;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm_fp8: dropout counter overflow");
+  p.stagger_10ns = (int)(a->K / BK8) * 60;     // ~0.6 us per k-step of one 256x128 tile running alone
+#ifdef NBEST_EXPERIMENTS
+  if (const char* e = getenv("NBEST_GEMM8_STAGGER")) p.stagger_10ns = atoi(e);
+#endif
   const int grid = p.tiles_m * p.tiles_n;
-  constexpr int lds_bytes = 4 * 2 * 256 * BK8;
+  constexpr int lds4 = 4 * (256 + 256) * BK8, lds2 = 3 * (256 + 128) * BK8;
   hipStream_t st = (hipStream_t)stream;
 #define L8(E)                                                                                                          \
   case E:                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)gemm8_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);    \
-    gemm8_kernel<E><<<grid, 512, lds_bytes, st>>>(p);                                                                  \
+    if (wn == 4) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)gemm8_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);    \
+      gemm8_kernel<E, 4><<<grid, 512, lds4, st>>>(p);                                                                  \
+    } else {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)gemm8_kernel<E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);    \
+      gemm8_kernel<E, 2><<<grid, 256, lds2, st>>>(p);                                                                  \
+    }                                                                                                                  \
     break;
   switch (epi) {
     L8(NBEST_EPI_NONE) L8(NBEST_EPI_BIAS) L8(NBEST_EPI_BIAS_GELU) L8(NBEST_EPI_BIAS_DROP_RES) L8(NBEST_EPI_DGELU) L8(NBEST_EPI_RES)

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_fast_kernel(const bf16* __r
           o[0][1] = ((h0 >> 16) >= drop.thr16) ? o[0][1] * drop.scale : 0.f;
           o[1][0] = ((h1 & 0xFFFFu) >= drop.thr16) ? o[1][0] * drop.scale : 0.f;
           o[1][1] = ((h1 >> 16) >= drop.thr16) ? o[1][1] * drop.scale : 0.f;
-          *(uint2*)(dx_drop + off) = uint2{pack_bf16x2(o[0]), pack_bf16x2(o[1])};
+          if (dx_drop) *(uint2*)(dx_drop + off) = uint2{pack_bf16x2(o[0]), pack_bf16x2(o[1])};   // (null: only its e4m3 copy is wanted)
         }
         if (DBIAS) { ad[i][0] += o[0]; ad[i][1] += o[1]; }
         if (f8.amax_new) {   // o = the gradient the dense-layer dgrad / wgrad GEMMs read (after the dropout mask)
@@ -714,7 +714,7 @@ int nbest_internal_layernorm_bwd8(const void* dy, const void* x, const float* st
   NB_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && ws && M > 0, NBEST_ERR_ARG, "layernorm_bwd: null pointer");
   NB_CHECK(ws_bytes >= nbest_rowred_ws_bytes(M, H), NBEST_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
   const DropCfg d = make_drop(drop_p, seed, drop_stream);
-  NB_CHECK(d.thr16 == 0 || (dx_drop && dx_drop != dx), NBEST_ERR_ARG, "layernorm_bwd: dropout needs a separate dx_drop buffer");
+  NB_CHECK(d.thr16 == 0 || (dx_drop && dx_drop != dx) || (!dx_drop && f8.out8), NBEST_ERR_ARG, "layernorm_bwd: dropout needs a separate dx_drop buffer");
   NB_CHECK(M * (int64_t)H < (int64_t)1 << 32 || d.thr16 == 0, NBEST_ERR_SHAPE, "layernorm_bwd: dropout counter overflow");
   hipStream_t st = (hipStream_t)stream;
   int nblk = (int)((M + 31) / 32 < 1 ? 1 : ((M + 31) / 32 > kMaxLnBwdBlocks ? kMaxLnBwdBlocks : (M + 31) / 32));

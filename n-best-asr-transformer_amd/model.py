@@ -210,6 +210,7 @@ class NBestSTCModel(nn.Module):
         d.seed = self._step_seed()
         if self.fp8_forward:
             d.w8, d.w8_inv_scale = self.arena.w8.data_ptr(), self.arena.w8_inv_scale.data_ptr()
+        self._set_fp8_backward(d)    # the forward leaves out the bf16 tensors an fp8 backward will not read
         out = C.c_void_p()
         hb.check(hb.lib().nbest_encoder_forward(C.byref(d), hb.ptr(self.arena.weights), hb.ptr(self.arena.p), hb.ptr(ids),
                                                 hb.ptr(seg), hb.ptr(pos), hb.ptr(mask), hb.ptr(ps.act), ps.act.numel(),
@@ -222,13 +223,17 @@ class NBestSTCModel(nn.Module):
         ps.hidden = ps.act[off:off + M * H * esz].view(self.compute_dtype).view(M, H)
         return ps.hidden
 
-    def _backward_pass(self, ps, dcls, accumulate, chunks=None, on_chunk_done=None):
-        cfg = self.cfg
+    def _set_fp8_backward(self, d):
+        """descriptor fields of the fp8 backward; the same values in the forward and the backward of one step"""
         if self.fp8_backward:
-            a, d = self.arena, ps.desc
+            a = self.arena
             d.w8t = a.w8t.data_ptr()
             d.gamax_prev, d.gamax_new = a.gamax[self._gamax_gen].data_ptr(), a.gamax[1 - self._gamax_gen].data_ptr()
             d.fp8_bwd = int(self._gamax_valid)
+
+    def _backward_pass(self, ps, dcls, accumulate, chunks=None, on_chunk_done=None):
+        cfg = self.cfg
+        self._set_fp8_backward(ps.desc)
         dh = hb.cls_grad_scatter(dcls, ps.B, ps.S, cfg.hidden_size, self.compute_dtype)
         ids, seg, pos, mask = ps.inputs
         L = cfg.num_hidden_layers

@@ -23,7 +23,15 @@ for nm, N, K, epi in (("qkv", 3 * H, H, hb.EPI_BIAS), ("attn_out", H, H, hb.EPI_
     kw = dict(R=R, drop_p=0.1, seed=1) if epi == hb.EPI_BIAS_DROP_RES else {}
     t16 = timeit(lambda: hb.gemm(A, W, M, N, K, epilogue=epi, bias=bias, out=out, U=U if epi == hb.EPI_BIAS_GELU else None, **kw))
     t8 = timeit(lambda: hb.gemm_fp8(A8, W8, M, N, K, bias, 1.0, epilogue=epi, out=out, **kw))
-    print("%-9s N=%4d K=%4d epi %d   bf16 %7.1f us %6.0f TF/s | fp8 %7.1f us %6.0f TF/s  (x%.2f)" % (nm, N, K, epi, t16 * 1e3, fl / t16 / 1e9, t8 * 1e3, fl / t8 / 1e9, t16 / t8), flush=True)
+    extra = ""
+    if os.environ.get("NBEST_LIB"):       # diag build: both tile variants (NBEST_GEMM8_WN)
+        for wn, stg in (("4", "0"), ("2", "0"), ("2", "300"), ("2", "600"), ("2", "1000"), ("2", "1500")):
+            os.environ["NBEST_GEMM8_WN"] = wn
+            os.environ["NBEST_GEMM8_STAGGER"] = stg
+            t = timeit(lambda: hb.gemm_fp8(A8, W8, M, N, K, bias, 1.0, epilogue=epi, out=out, **kw))
+            extra += "  wn%s/%s %5.1f" % (wn, stg, t * 1e3)
+        del os.environ["NBEST_GEMM8_WN"], os.environ["NBEST_GEMM8_STAGGER"]
+    print("%-9s N=%4d K=%4d epi %d   bf16 %7.1f us %6.0f TF/s | fp8 %7.1f us %6.0f TF/s  (x%.2f)%s" % (nm, N, K, epi, t16 * 1e3, fl / t16 / 1e9, t8 * 1e3, fl / t8 / 1e9, t16 / t8, extra), flush=True)
 
 # weight gradients: bf16 TT kernel vs fp8 transposed-read kernel (K = M tokens)
 for nm, Mo, No in (("qkv", 3 * H, H), ("attn_out", H, H), ("ffn_up", F, H), ("ffn_down", H, F)):
