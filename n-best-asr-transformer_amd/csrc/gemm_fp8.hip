@@ -26,9 +26,16 @@ constexpr int BK8 = 64;
 #define NBEST_DIAG 0
 #endif
 // timing-only ablations of the epilogue (`make diag DIAG=<mask>`, results are wrong): 256 no GELU math, 512 no 8-bit stores,
-// 1024 no bf16 store, 2048 no main loop, 4096 nontemporal stores; of the ping-pong main loop: 1 no in-loop DMA, 2 no fragment
+// 1024 no bf16 store, 2048 no main loop; of the ping-pong main loop: 1 no in-loop DMA, 2 no fragment
 // reads, 4 no MFMA
 constexpr int DIAG8 = NBEST_DIAG;
+// Epilogue stores are streaming (nontemporal): the outputs (50 - 400 MB per GEMM) otherwise wash the weights and the
+// activation panel out of the 4 MiB L2 of every XCD while other tiles still read them (FFN-up 175 -> 163 us).
+constexpr bool kStreamStores = true;
+template <typename V> __device__ __forceinline__ void st_out(V* p, V v) {
+  if (kStreamStores) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
 struct GemmP8 {
   const uint8_t* A; const uint8_t* B; bf16* C; const float* bias; const bf16* R; uint8_t* U; uint8_t* C8;
@@ -41,12 +48,8 @@ struct GemmP8 {
   Fp8Grad c8g;                 // DGELU: e4m3 copy of the output gradient (scaled by ITS previous amax) + its new amax
   float* colpart;              // DGELU: fused column sums of the output (bias gradient), partial rows [tiles_m * 2][N]
   DropCfg drop;
-  int stagger_10ns;            // WN = 2: start delay of every second first-round workgroup of a CU (units of the 100 MHz clock)
 };
 
-// Arrival counters per CU (key: XCC | SE | SH | CU of HW_ID), never reset: only the PARITY of a workgroup's arrival number
-// is used, and the two workgroups that share a CU in the first round of a launch draw consecutive numbers.
-__device__ unsigned g_cu_arrivals[2048];
 #ifdef NBEST_EXPERIMENTS
 __device__ unsigned long long* g_trace8;   // per workgroup: key | late << 16, t_start, t_main_end, t_end (100 MHz clock)
 #endif
@@ -80,10 +83,9 @@ __device__ __forceinline__ i32x8 read_frag8(const char* tile, int row_base, int 
 template <int N> __device__ __forceinline__ void wait_vm8() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // WN = 4: 256x256 tile, 8 waves, ONE workgroup per CU (4-stage ring = 128 KiB), the two wave groups ping-pong.
-// WN = 2: 256x128 tile, 4 waves, TWO workgroups per CU (3-stage ring = 72 KiB each, <= 256 registers): no choreography
-//         between them - while one workgroup is in its (VALU-bound: GELU, fp8 packing) epilogue the other one's main loop owns
-//         the matrix pipe.  Pays 1.5x the LDS-DMA bytes per flop; chosen for the shapes whose epilogue is as long as their
-//         main loop (K = 768).
+// WN = 2: 256x128 tile, 4 waves, TWO workgroups per CU (3-stage ring = 72 KiB each, <= 256 registers), no choreography
+//         between them.  Pays 1.5x the LDS-DMA bytes per flop; ties with WN = 4 on the layer shapes except the small
+//         N = K = 768 ones, where twice as many tiles fill the last round better.
 template <int EPI, int WN>
 __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -193,9 +195,9 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
   } else {
     // ---- two independent workgroups per CU: plain 3-stage ring, one barrier per k-step ----
-    // Left alone, the two workgroups of a CU start together and stay in phase: both in the main loop (sharing the matrix
-    // pipe), then both in the epilogue (sharing VALU and the store path) - nothing overlaps.  One of the two therefore
-    // starts late by about one main loop; later rounds inherit the offset (a workgroup starts when its predecessor ends).
+    // (The two workgroups of a CU drift out of phase by themselves - tools/gemm8_trace.py - so the epilogue of one does
+    // overlap the main loop of the other; what it cannot buy back is that a main loop running alone has only its own two
+    // stages in flight.)
 #ifdef NBEST_EXPERIMENTS
     if (g_trace8 && tid == 0) {
       unsigned hw, xcc;
@@ -205,22 +207,6 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
       g_trace8[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    if (p.stagger_10ns > 0 && blockIdx.x < 512) {
-      int late = 0;
-      if (tid == 0) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const unsigned key = ((xcc & 7) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
-        late = atomicAdd(&g_cu_arrivals[key], 1u) & 1;
-      }
-      late = __builtin_amdgcn_readfirstlane(late);
-      if (wave == 0 && late) {
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        while ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) < p.stagger_10ns) __builtin_amdgcn_s_sleep(32);
-      }
-      __builtin_amdgcn_s_barrier();
-    }
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
@@ -303,12 +289,9 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
           gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);
           v[e] *= cdf;
         }
-        if (DIAG8 & 4096) {
-          __builtin_nontemporal_store(i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, (i32x2*)(p.U + m * p.ldu + en8));
-          __builtin_nontemporal_store(i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)}, (i32x2*)(p.C8 + m * p.ldc8 + en8));
-        } else if (!(DIAG8 & 512)) {
-        *(i32x2*)(p.U + m * p.ldu + en8) = i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)};
-        *(i32x2*)(p.C8 + m * p.ldc8 + en8) = i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)};
+        if (!(DIAG8 & 512)) {
+          st_out((i32x2*)(p.U + m * p.ldu + en8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)});
+          st_out((i32x2*)(p.C8 + m * p.ldc8 + en8), i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)});
         } else if (gp[0] + gp[3] + gp[5] == 123.f) p.U[0] = 1;
       }
       if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
@@ -335,18 +318,17 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
             float q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) q[e] = v[e] * c8s;
-            *(i32x2*)(p.c8g.out8 + m * p.ldc8 + en8) = i32x2{(int)fp8_pack4(q), (int)fp8_pack4(q + 4)};
+            st_out((i32x2*)(p.c8g.out8 + m * p.ldc8 + en8), i32x2{(int)fp8_pack4(q), (int)fp8_pack4(q + 4)});
           }
         }
       }
       if ((EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_DGELU) && !p.C) continue;   // only the e4m3 copy is wanted
-      if (DIAG8 & 4096) {
+      if (!(DIAG8 & 1024)) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        __builtin_nontemporal_store(o, (bf16x8*)(p.C + m * p.ldc + en8));
-      } else if (!(DIAG8 & 1024)) Vec8<bf16>::store(p.C + m * p.ldc + en8, v);
-      else if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 123.f) p.C[0] = (bf16)1.f;
+        st_out((bf16x8*)(p.C + m * p.ldc + en8), o);
+      } else if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 123.f) p.C[0] = (bf16)1.f;
     }
     asm volatile("" ::: "memory");
   }
@@ -783,8 +765,9 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
   p.A = (const uint8_t*)a->A; p.B = (const uint8_t*)a->B; p.C = (bf16*)a->C; p.bias = a->bias; p.R = (const bf16*)a->R;
   p.U = (uint8_t*)a->U; p.C8 = (uint8_t*)a->C8;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldu = a->ldu; p.ldc8 = a->ldc8;
-  // two small workgroups per CU where the epilogue weighs as much as the main loop (short K), one big one elsewhere
-  int wn = (a->K <= 1024 && (epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_DGELU)) ? 2 : 4;
+  // 256x128 tiles, two workgroups per CU, where 256x256 tiles leave the last round half empty and the main loop is short
+  // (N = K = 768: 384 big tiles on 256 CUs; 47 -> 41 us); the big ping-pong tile elsewhere (the two tie on the other shapes)
+  int wn = (a->N * (int64_t)((a->M + 255) / 256) <= 3 * 128 * 256 && a->K <= 1024) ? 2 : 4;
 #ifdef NBEST_EXPERIMENTS
   if (const char* e = getenv("NBEST_GEMM8_WN")) if (e[0] == '2' || e[0] == '4') wn = e[0] - '0';
 #endif
@@ -800,10 +783,7 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
   p.colpart = (epi == NBEST_EPI_DGELU && a->colsum_out) ? (float*)a->ws : nullptr;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm_fp8: dropout counter overflow");
-  p.stagger_10ns = (int)(a->K / BK8) * 60;     // ~0.6 us per k-step of one 256x128 tile running alone
-#ifdef NBEST_EXPERIMENTS
-  if (const char* e = getenv("NBEST_GEMM8_STAGGER")) p.stagger_10ns = atoi(e);
-#endif
+
   const int grid = p.tiles_m * p.tiles_n;
   constexpr int lds4 = 4 * (256 + 256) * BK8, lds2 = 3 * (256 + 128) * BK8;
   hipStream_t st = (hipStream_t)stream;
