@@ -96,6 +96,16 @@ template <> struct Vec8<bf16> {
   }
 };
 
+// Streaming (nontemporal) store: for GEMM / attention outputs of tens to hundreds of MB, which otherwise wash the operands
+// other tiles still read out of the 4 MiB L2 of every XCD.
+template <typename V> __device__ __forceinline__ void st_stream(V* p, V v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream_bf16x8(bf16* p, const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+  __builtin_nontemporal_store(o, (bf16x8*)p);
+}
+
 // ---- wave64 / block reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

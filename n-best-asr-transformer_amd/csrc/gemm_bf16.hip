@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
         v[e] *= cdf;
       }
-      *(i32x2*)((uint8_t*)p.U + m * p.ldu + n8) = i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)};
+      st_stream((i32x2*)((uint8_t*)p.U + m * p.ldu + n8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)});
     }
     if (EPI == NBEST_EPI_BIAS_DROP_RES) {
       if (p.drop.thr16) {
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= gd[e];
     }
-    Vec8<bf16>::store((bf16*)p.C + m * p.ldc + n8, v);
+    st_stream_bf16x8((bf16*)p.C + m * p.ldc + n8, v);
     if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) colacc[e] += v[e];
