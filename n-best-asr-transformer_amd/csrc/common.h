@@ -98,12 +98,27 @@ template <> struct Vec8<bf16> {
 
 // Streaming (nontemporal) store: for GEMM / attention outputs of tens to hundreds of MB, which otherwise wash the operands
 // other tiles still read out of the 4 MiB L2 of every XCD.
-template <typename V> __device__ __forceinline__ void st_stream(V* p, V v) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ void st_stream_bf16x8(bf16* p, const float* v) {
+// (inline asm: written as `nt ? __builtin_nontemporal_store : plain store` the optimiser merges the two stores of the diamond
+// into one plain store and the hint is gone)
+template <typename V> __device__ __forceinline__ void st_stream(V* p, V v, bool nt) {
+  static_assert(sizeof(V) == 8 || sizeof(V) == 16, "st_stream: 8- or 16-byte vectors");
+  if (!nt) { *p = v; return; }
+  if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_stream_bf16x8(bf16* p, const float* v, bool nt) {
   bf16x8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
-  __builtin_nontemporal_store(o, (bf16x8*)p);
+  st_stream((bf16x8*)p, o, nt);
+}
+// host side: which GEMM outputs are streamed (bytes of the bf16 output)
+inline bool nb_stream_output(int64_t out_bytes) {
+  int64_t min_mb = 0;
+#ifdef NBEST_EXPERIMENTS
+  if (const char* e = getenv("NBEST_NT_MIN_MB")) min_mb = atoll(e);
+#endif
+  return out_bytes >= (min_mb << 20);
 }
 
 // ---- wave64 / block reductions ----------------------------------------------------------------

@@ -31,6 +31,7 @@ struct GemmP {
   int tiles_m, tiles_n, splits, accumulate;
   uint32_t a_bytes, b_bytes;
   DropCfg drop;
+  int stream_out;     // epilogue stores are nontemporal (common.h st_stream)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
         v[e] *= cdf;
       }
-      st_stream((i32x2*)((uint8_t*)p.U + m * p.ldu + n8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)});
+      st_stream((i32x2*)((uint8_t*)p.U + m * p.ldu + n8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
     }
     if (EPI == NBEST_EPI_BIAS_DROP_RES) {
       if (p.drop.thr16) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= gd[e];
     }
-    st_stream_bf16x8((bf16*)p.C + m * p.ldc + n8, v);
+    st_stream_bf16x8((bf16*)p.C + m * p.ldc + n8, v, p.stream_out);
     if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) colacc[e] += v[e];
@@ -377,6 +378,7 @@ int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st) {
   NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm(bf16): operand larger than 4 GiB");
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
+  p.stream_out = nb_stream_output(a->M * a->N * 2) ? 1 : 0;
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm(bf16): dropout counter overflow");
   const int epi = a->epilogue;
   if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)

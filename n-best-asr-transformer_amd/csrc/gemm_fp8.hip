@@ -29,13 +29,8 @@ constexpr int BK8 = 64;
 // 1024 no bf16 store, 2048 no main loop; of the ping-pong main loop: 1 no in-loop DMA, 2 no fragment
 // reads, 4 no MFMA
 constexpr int DIAG8 = NBEST_DIAG;
-// Epilogue stores are streaming (nontemporal): the outputs (50 - 400 MB per GEMM) otherwise wash the weights and the
-// activation panel out of the 4 MiB L2 of every XCD while other tiles still read them (FFN-up 175 -> 163 us).
-constexpr bool kStreamStores = true;
-template <typename V> __device__ __forceinline__ void st_out(V* p, V v) {
-  if (kStreamStores) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
+// Epilogue stores are streaming (nontemporal, common.h st_stream): the outputs (50 - 400 MB per GEMM) otherwise wash the
+// weights and the activation panel out of the 4 MiB L2 of every XCD while other tiles still read them (FFN-up 175 -> 163 us).
 
 struct GemmP8 {
   const uint8_t* A; const uint8_t* B; bf16* C; const float* bias; const bf16* R; uint8_t* U; uint8_t* C8;
@@ -48,6 +43,7 @@ struct GemmP8 {
   Fp8Grad c8g;                 // DGELU: e4m3 copy of the output gradient (scaled by ITS previous amax) + its new amax
   float* colpart;              // DGELU: fused column sums of the output (bias gradient), partial rows [tiles_m * 2][N]
   DropCfg drop;
+  int stream_out;
 };
 
 #ifdef NBEST_EXPERIMENTS
@@ -290,8 +286,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
           v[e] *= cdf;
         }
         if (!(DIAG8 & 512)) {
-          st_out((i32x2*)(p.U + m * p.ldu + en8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)});
-          st_out((i32x2*)(p.C8 + m * p.ldc8 + en8), i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)});
+          st_stream((i32x2*)(p.U + m * p.ldu + en8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
+          st_stream((i32x2*)(p.C8 + m * p.ldc8 + en8), i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)}, p.stream_out);
         } else if (gp[0] + gp[3] + gp[5] == 123.f) p.U[0] = 1;
       }
       if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
@@ -318,7 +314,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
             float q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) q[e] = v[e] * c8s;
-            st_out((i32x2*)(p.c8g.out8 + m * p.ldc8 + en8), i32x2{(int)fp8_pack4(q), (int)fp8_pack4(q + 4)});
+            st_stream((i32x2*)(p.c8g.out8 + m * p.ldc8 + en8), i32x2{(int)fp8_pack4(q), (int)fp8_pack4(q + 4)}, p.stream_out);
           }
         }
       }
@@ -327,7 +323,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        st_out((bf16x8*)(p.C + m * p.ldc + en8), o);
+        st_stream((bf16x8*)(p.C + m * p.ldc + en8), o, p.stream_out);
       } else if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 123.f) p.C[0] = (bf16)1.f;
     }
     asm volatile("" ::: "memory");
@@ -782,6 +778,7 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
   p.c8g = Fp8Grad{epi == NBEST_EPI_DGELU ? (uint8_t*)a->C8 : nullptr, a->c8_amax_prev, a->c8_amax_new};
   p.colpart = (epi == NBEST_EPI_DGELU && a->colsum_out) ? (float*)a->ws : nullptr;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
+  p.stream_out = nb_stream_output(a->M * a->N * 2) ? 1 : 0;
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm_fp8: dropout counter overflow");
 
   const int grid = p.tiles_m * p.tiles_n;
