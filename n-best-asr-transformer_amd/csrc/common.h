@@ -201,13 +201,12 @@ __device__ __forceinline__ float dgelu_fast(float u) {
 // 1/200 over [-0.13, 1.145] (g' lies in [-0.129, 1.129]) with 0 and 1 represented EXACTLY (saturated units and dead units
 // carry no error); |error| <= 0.0025, the size of a bf16 ulp at 1.  Halves the bytes of the largest tensor the forward writes
 // only for the backward to read once.
+// v_cvt_pk_u8_f32 converts (round to nearest even, saturating to [0, 255]: tools/micro/cvt_u8_probe.hip) AND inserts the byte:
+// one instruction per value where clamp + convert + shift/or took four.
 __device__ __forceinline__ uint32_t gd_pack4(const float* g) {
   uint32_t w = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float x = __builtin_amdgcn_fmed3f(fmaf(g[e], 200.f, 26.5f), 0.f, 255.f);   // +0.5 then truncate = round half up
-    w |= (uint32_t)x << (8 * e);
-  }
+  for (int e = 0; e < 4; ++e) w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[e], 200.f, 26.f), e, w);
   return w;
 }
 __device__ __forceinline__ void gd_unpack4(uint32_t w, float* g) {

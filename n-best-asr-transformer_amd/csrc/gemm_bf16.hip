@@ -215,16 +215,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   float colacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // element offsets of this lane's 8-column group in the row-major outputs, advanced by 8 rows per iteration
+  // (m * ld afresh for every row = quarter-rate 64-bit multiplies in a VALU-bound epilogue)
+  const int64_t er0 = m0 + wm * 64 + (lane >> 3), ec8 = n0 + wn * 64 + (lane & 7) * 8;
+  int64_t oC = er0 * p.ldc + ec8, oU = er0 * p.ldu + ec8, oS = ((int64_t)z * p.M + er0) * p.N + ec8;
+  const int64_t sC = 8 * p.ldc, sU = 8 * p.ldu, sS = 8 * p.N;
+  uint32_t dbase = (uint32_t)(er0 * p.N + ec8);
+  const uint32_t sD = 8u * (uint32_t)p.N;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < 8; ++it, oC += sC, oU += sU, oS += sS, dbase += sD) {
     const int pidx = it * 64 + lane, row = pidx >> 3, c8 = pidx & 7;
     const int64_t m = m0 + wm * 64 + row;
-    const int64_t n8 = n0 + wn * 64 + c8 * 8;
     f32x4 v0 = *(const f32x4*)(ep + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
     f32x4 v1 = *(const f32x4*)(ep + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
     if (m >= p.M) continue;
     if (EPI == NBEST_EPI_F32_SPLITK) {
-      float* c = (p.splits > 1) ? p.slab + ((int64_t)z * p.M + m) * p.N + n8 : (float*)p.C + m * p.ldc + n8;
+      float* c = (p.splits > 1) ? p.slab + oS : (float*)p.C + oC;
       if (p.splits == 1 && p.accumulate) { v0 += *(const f32x4*)c; v1 += *(const f32x4*)(c + 4); }
       *(f32x4*)c = v0;
       *(f32x4*)(c + 4) = v1;
@@ -244,12 +250,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
         gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
         v[e] *= cdf;
       }
-      st_stream((i32x2*)((uint8_t*)p.U + m * p.ldu + n8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
+      st_stream((i32x2*)((uint8_t*)p.U + oU), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
     }
     if (EPI == NBEST_EPI_BIAS_DROP_RES) {
       if (p.drop.thr16) {
-        const uint32_t base = (uint32_t)(m * p.N + n8);
-        const uint32_t k = nb_keep4(p.drop, base) | (nb_keep4(p.drop, base + 4) << 4);
+        const uint32_t k = nb_keep4(p.drop, dbase) | (nb_keep4(p.drop, dbase + 4) << 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
       }
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= gd[e];
     }
-    st_stream_bf16x8((bf16*)p.C + m * p.ldc + n8, v, p.stream_out);
+    st_stream_bf16x8((bf16*)p.C + oC, v, p.stream_out);
     if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) colacc[e] += v[e];

@@ -371,6 +371,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   }
   __builtin_amdgcn_s_barrier();   // every wave has finished reading the operand ring
   asm volatile("" ::: "memory");
+  // element offsets of this lane's 8-column group in the row-major outputs, advanced by 8 rows per iteration (m * ld afresh for
+  // every row = quarter-rate 64-bit multiplies in a VALU-bound epilogue)
+  int64_t oC = erow0 * p.ldc + en8, oU = erow0 * p.ldu + en8;
+  int64_t oS = ((int64_t)z * p.M + erow0) * p.N + en8;
+  const int64_t sC = 8 * p.ldc, sU = 8 * p.ldu, sS = 8 * p.N;
+  uint32_t dbase = (uint32_t)(erow0 * p.N + en8);
+  const uint32_t sD = 8u * (uint32_t)p.N;
 #pragma unroll
   for (int c = 0; c < TMt / 2; ++c) {
 #pragma unroll
@@ -387,17 +394,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     for (int it = 0; it < 4; ++it) {
       const int pidx = it * 64 + lane, row = pidx >> 3, c8 = pidx & 7;
       const int64_t m = m0 + wm * WTM + c * 32 + row;
-      const int64_t n8 = en8;
       f32x4 v0 = *(const f32x4*)(ep + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
       f32x4 v1 = *(const f32x4*)(ep + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
-      if (m >= p.M) continue;
+      if (m < p.M) {
       if (EPI == NBEST_EPI_F32_SPLITK) {
-        float* cp = (p.splits > 1) ? p.slab + ((int64_t)z * p.M + m) * p.N + n8 : (float*)p.C + m * p.ldc + n8;
+        float* cp = (p.splits > 1) ? p.slab + oS : (float*)p.C + oC;
         if (p.splits == 1 && p.accumulate) { v0 += *(const f32x4*)cp; v1 += *(const f32x4*)(cp + 4); }
         *(f32x4*)cp = v0;
         *(f32x4*)(cp + 4) = v1;
-        continue;
-      }
+      } else {
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (kHasBias) {
 #pragma unroll
@@ -412,11 +417,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
           gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
           v[e] *= cdf;
         }
-        st_stream((i32x2*)((uint8_t*)p.U + m * p.ldu + n8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
+        st_stream((i32x2*)((uint8_t*)p.U + oU), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
       }
       if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
-        const uint32_t base = (uint32_t)(m * p.N + n8);
-        const uint32_t k = nb_keep4(p.drop, base) | (nb_keep4(p.drop, base + 4) << 4);
+        const uint32_t k = nb_keep4(p.drop, dbase) | (nb_keep4(p.drop, dbase + 4) << 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
       }
@@ -432,11 +436,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gd[e];
       }
-      st_stream_bf16x8((bf16*)p.C + m * p.ldc + n8, v, p.stream_out);
+      st_stream_bf16x8((bf16*)p.C + oC, v, p.stream_out);
       if (EPI != NBEST_EPI_F32_SPLITK && p.colpart) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) colacc[e] += v[e];
       }
+      }
+      }
+      oC += sC; oU += sU; oS += sS; dbase += sD;
     }
     asm volatile("" ::: "memory");
   }

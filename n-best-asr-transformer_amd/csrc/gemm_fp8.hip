@@ -254,6 +254,12 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
   __builtin_amdgcn_s_barrier();   // every wave has finished reading the operand ring
   asm volatile("" ::: "memory");
   const int hh = lane >> 5, wrow = lane & 31;
+  // element offsets of this lane's 8-column group in the row-major outputs, advanced by 8 rows per iteration (computing
+  // m * ld afresh for every row costs quarter-rate 64-bit multiplies: 15 % of the VALU work of the GELU epilogue)
+  int64_t oC = erow0 * p.ldc + en8, oU = erow0 * p.ldu + en8, oC8 = erow0 * p.ldc8 + en8;
+  const int64_t sC = 8 * p.ldc, sU = 8 * p.ldu, sC8 = 8 * p.ldc8;
+  uint32_t dbase = (uint32_t)(erow0 * p.N + en8);
+  const uint32_t sD = 8u * (uint32_t)p.N;
 #pragma unroll
   for (int c = 0; c < TMb; ++c) {
 #pragma unroll
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
       const int64_t m = m0 + wm * WTM + c * 32 + row;
       const f32x4 v0 = *(const f32x4*)(ep + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
       const f32x4 v1 = *(const f32x4*)(ep + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
-      if (m >= p.M) continue;
+      if (m < p.M) {
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = fmaf(v[e], oscale, pb0[e]); v[4 + e] = fmaf(v[4 + e], oscale, pb1[e]); }   // (no bias: pb = 0)
@@ -286,13 +292,12 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
           v[e] *= cdf;
         }
         if (!(DIAG8 & 512)) {
-          st_stream((i32x2*)(p.U + m * p.ldu + en8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
-          st_stream((i32x2*)(p.C8 + m * p.ldc8 + en8), i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)}, p.stream_out);
+          st_stream((i32x2*)(p.U + oU), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
+          st_stream((i32x2*)(p.C8 + oC8), i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)}, p.stream_out);
         } else if (gp[0] + gp[3] + gp[5] == 123.f) p.U[0] = 1;
       }
       if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
-        const uint32_t base = (uint32_t)(m * p.N + en8);
-        const uint32_t k = nb_keep4(p.drop, base) | (nb_keep4(p.drop, base + 4) << 4);
+        const uint32_t k = nb_keep4(p.drop, dbase) | (nb_keep4(p.drop, dbase + 4) << 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (k >> e & 1) ? v[e] * p.drop.scale : 0.f;
       }
@@ -314,17 +319,19 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
             float q[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) q[e] = v[e] * c8s;
-            st_stream((i32x2*)(p.c8g.out8 + m * p.ldc8 + en8), i32x2{(int)fp8_pack4(q), (int)fp8_pack4(q + 4)}, p.stream_out);
+            st_stream((i32x2*)(p.c8g.out8 + oC8), i32x2{(int)fp8_pack4(q), (int)fp8_pack4(q + 4)}, p.stream_out);
           }
         }
       }
-      if ((EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_DGELU) && !p.C) continue;   // only the e4m3 copy is wanted
-      if (!(DIAG8 & 1024)) {
+      if ((EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_DGELU) && !p.C) {   // only the e4m3 copy is wanted
+      } else if (!(DIAG8 & 1024)) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        st_stream((bf16x8*)(p.C + m * p.ldc + en8), o, p.stream_out);
+        st_stream((bf16x8*)(p.C + oC), o, p.stream_out);
       } else if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 123.f) p.C[0] = (bf16)1.f;
+      }
+      oC += sC; oU += sU; oC8 += sC8; dbase += sD;
     }
     asm volatile("" ::: "memory");
   }

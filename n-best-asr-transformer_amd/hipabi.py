@@ -220,7 +220,7 @@ def gelu_d_decode(U):
 
 
 def gelu_d_encode(g):
-    return torch.clamp(torch.floor(g.float() * 200.0 + 26.5), 0, 255).to(torch.uint8)
+    return torch.clamp(torch.round(g.float() * 200.0 + 26.0), 0, 255).to(torch.uint8)      # round half to even, as the kernels
 
 
 def cast_fp8(x):

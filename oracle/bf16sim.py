@@ -50,8 +50,8 @@ class _RoundWeight(torch.autograd.Function):
 
 
 def _q8(g):
-    """gelu'(u) as the bf16 path keeps it: 8-bit fixed point, q = round(200 g') + 26 (step 1/200, 0 and 1 exact)"""
-    return (torch.clamp(torch.floor(g * 200.0 + 26.5), 0, 255) - 26.0) / 200.0
+    """gelu'(u) as the bf16 path keeps it: 8-bit fixed point, q = round(200 g' + 26) (half to even; step 1/200, 0 and 1 exact)"""
+    return (torch.clamp(torch.round(g * 200.0 + 26.0), 0, 255) - 26.0) / 200.0
 
 
 class _GeluStore(torch.autograd.Function):
