@@ -186,6 +186,23 @@ __device__ __forceinline__ void gelu_parts_fast(float u, float& cdf, float& e) {
   const float erf_abs = fmaf(-poly * t, e, 1.0f);   // erf(|u|/sqrt2)
   cdf = fmaf(0.5f, copysignf(erf_abs, u), 0.5f);
 }
+// The same on a PAIR of values with packed fp32 math (v_pk_mul / v_pk_fma: two lanes' worth per instruction); returns
+// gelu(u) in h and gelu'(u) in g.  The GEMM epilogues that apply GELU are VALU-bound: this form is what they call.
+__device__ __forceinline__ void gelu_pair_fast(f32x2 u, f32x2& h, f32x2& g) {
+  const f32x2 au = {fabsf(u[0]), fabsf(u[1])};
+  const f32x2 d = au * 0.23164190f + 1.0f;                               // 1 + 0.3275911 |u| / sqrt2
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 poly = t * (-0.5f * 1.061405429f) + (0.5f * 1.453152027f);       // the polynomial times -1/2 (folded into its coefficients)
+  poly = poly * t + (-0.5f * 1.421413741f);
+  poly = poly * t + (0.5f * 0.284496736f);
+  poly = poly * t + (-0.5f * 0.254829592f);
+  const f32x2 x2 = (u * u) * (-0.5f * 1.4426950408889634f);              // exp(-u^2/2) = exp2(-u^2/2 log2 e)
+  const f32x2 e = {__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
+  const f32x2 half_erf = (poly * t) * e + 0.5f;                          // erf(|u|/sqrt2) / 2
+  const f32x2 cdf = {0.5f + copysignf(half_erf[0], u[0]), 0.5f + copysignf(half_erf[1], u[1])};
+  g = (u * 0.39894228040143267794f) * e + cdf;
+  h = u * cdf;
+}
 __device__ __forceinline__ float gelu_fast(float u) {
   float cdf, e;
   gelu_parts_fast(u, cdf, e);

@@ -411,11 +411,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       if (EPI == NBEST_EPI_BIAS_GELU) {
         float gp[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float cdf, ex;
-          gelu_parts_fast(v[e], cdf, ex);
-          gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
-          v[e] *= cdf;
+        for (int e = 0; e < 8; e += 2) {
+          f32x2 h2, g2;   // gelu(u), and gelu'(u) kept for the backward
+          gelu_pair_fast(f32x2{v[e], v[e + 1]}, h2, g2);
+          gp[e] = g2[0]; gp[e + 1] = g2[1]; v[e] = h2[0]; v[e + 1] = h2[1];
         }
         st_stream((i32x2*)((uint8_t*)p.U + oU), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
       }
@@ -633,11 +632,10 @@ __global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
         if (EPI == NBEST_EPI_BIAS_GELU) {
           float gp[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float cdf, ex;
-            gelu_parts_fast(v[e], cdf, ex);
-            gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // GELU'(u), kept for the backward
-            v[e] *= cdf;
+          for (int e = 0; e < 8; e += 2) {
+            f32x2 h2, g2;   // gelu(u), and gelu'(u) kept for the backward
+            gelu_pair_fast(f32x2{v[e], v[e + 1]}, h2, g2);
+            gp[e] = g2[0]; gp[e + 1] = g2[1]; v[e] = h2[0]; v[e + 1] = h2[1];
           }
           st_stream((i32x2*)((uint8_t*)p.U + m * p.ldu + en8), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
         }

@@ -284,12 +284,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
       if (EPI == NBEST_EPI_BIAS_GELU) {
         float gp[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float cdf, ex;
-          if (DIAG8 & 256) { gp[e] = v[e]; continue; }
-          gelu_parts_fast(v[e], cdf, ex);
-          gp[e] = fmaf(v[e] * 0.39894228040143267794f, ex, cdf);
-          v[e] *= cdf;
+        for (int e = 0; e < 8; e += 2) {
+          if (DIAG8 & 256) { gp[e] = v[e]; gp[e + 1] = v[e + 1]; continue; }
+          f32x2 h2, g2;
+          gelu_pair_fast(f32x2{v[e], v[e + 1]}, h2, g2);
+          gp[e] = g2[0]; gp[e + 1] = g2[1]; v[e] = h2[0]; v[e + 1] = h2[1];
         }
         if (!(DIAG8 & 512)) {
           st_stream((i32x2*)(p.U + oU), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
