@@ -57,6 +57,7 @@ CASES = ["bert_L2", "bert_L2_noseg", "xlmr_L2", "bert_L12",
          "xlmr_L12",             # BASELINE configs[2]: xlm-roberta-base, 12 layers, seq_len 128
          "xlmrL_L4_S256"]        # BASELINE configs[4] architecture: xlm-roberta-large shape, 4 layers, seq_len 256
 FLOOR_FACTOR = 1.5
+SMALL_FACTOR = 2.0      # tensors whose error statistic is a handful of correlated draws (see `dense` below): 2 x the worst of them
 
 
 def _cmp_floor(name, got, ref, floor_max):
@@ -121,7 +122,8 @@ def test_step_matches_reference_outputs(name, dtype, labels):
     # (sparse) embedding tables, and the STC heads, whose gradients are rank-B outer products of B <= 4 noisy rows
     dense = lambda n: int(np.prod(named[n].shape)) >= 4096 and n.startswith("bert_encoder.encoder.")
     ns_floor_of = {k[9:]: float(z[k][0]) for k in z.files if k.startswith("floor/ns/") and not k.endswith("attention.self.key.bias")}
-    # the others: their statistic is a handful of draws, so they are held to the worst such tensor of the oracle leg
+    # the others: their statistic is a handful of draws (a head's whole gradient error is ONE perturbed CLS row: the ratio of two
+    # such draws exceeds 1.5 a third of the time), so they are held to 2 x the worst such tensor of the oracle leg
     sparse_ns = max(v for n, v in ns_floor_of.items() if not dense(n))
     sparse_samp = max(float(z[k][0]) / max(float(z[k][1]), 1e-30) for k in z.files if k.startswith("floor/samp/") and not dense(k[11:])
                       and not k.endswith("attention.self.key.bias"))
@@ -148,7 +150,7 @@ def test_step_matches_reference_outputs(name, dtype, labels):
                 continue
             rel = abs(got - ref) / max(ref, 1e-6)
             ns_floor = ns_floor_of[name] if dense(name) else sparse_ns
-            if rel > (2e-3 if f32 else FLOOR_FACTOR * ns_floor) + (1e-7 if f32 else 1e-4) / max(ref, 1e-6):
+            if rel > (2e-3 if f32 else (FLOOR_FACTOR if dense(name) else SMALL_FACTOR) * ns_floor) + (1e-7 if f32 else 1e-4) / max(ref, 1e-6):
                 bad.append((key, got, ref, ns_floor))
             if "samp/" + name in z.files:
                 idx = torch.from_numpy(np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF).randint(0, g.numel(), size=512)).cuda()
@@ -159,7 +161,7 @@ def test_step_matches_reference_outputs(name, dtype, labels):
                     rows_ns.append((err / max(sim_err, 1e-30), err / max(sig, 1e-30), sim_err / max(sig, 1e-30), name))
                 else:
                     sim_err = sparse_samp * sig
-                lim = 2e-3 * sig + 1e-9 if f32 else FLOOR_FACTOR * sim_err + 2.0 ** -9 * sig
+                lim = 2e-3 * sig + 1e-9 if f32 else (FLOOR_FACTOR if dense(name) else SMALL_FACTOR) * sim_err + 2.0 ** -9 * sig
                 if err > lim:
                     bad.append(("samp/" + name, err, sim_err, sig))
         elif key.startswith("grad/") and not key.endswith("attention.self.key.bias"):
@@ -303,7 +305,7 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False, fp8_bwd=False):
         if f32:
             lim = 2e-3
         else:
-            lim = FLOOR_FACTOR * (sim_ns[n] if dense(n) else small_floor) + 1e-3
+            lim = (FLOOR_FACTOR * sim_ns[n] if dense(n) else SMALL_FACTOR * small_floor) + 1e-3
             worst = max(worst, (ns / max(sim_ns[n], 1e-30), n))
         assert ns <= lim, (n, ns, lim, sim_ns.get(n))
     if not f32:
