@@ -96,6 +96,15 @@ template <> struct Vec8<bf16> {
   }
 };
 
+// cache-policy bits of the LDS-DMA operand loads (aux of raw_ptr_buffer_load_lds: 1 = sc0, 2 = nt, 16 = sc1); experiments only
+#ifndef NBEST_DIAG
+#define NB_AUX_A 0
+#define NB_AUX_B 0
+#else
+#define NB_AUX_A ((NBEST_DIAG & 8192) ? 2 : 0)
+#define NB_AUX_B ((NBEST_DIAG & 16384) ? 2 : 0)
+#endif
+
 // Streaming (nontemporal) store: for GEMM / attention outputs of tens to hundreds of MB, which otherwise wash the operands
 // other tiles still read out of the 4 MiB L2 of every XCD.
 // (inline asm: written as `nt ? __builtin_nontemporal_store : plain store` the optimiser merges the two stores of the diamond

@@ -40,7 +40,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ---- staging: one operand tile, 4 LDS-DMA instructions per thread -------------------------------
-template <bool TR>
+template <bool TR, int AUX = 0>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, char* lds_tile, int64_t row0, int64_t k0, int64_t ld,
                                            int tid) {
   const int wave = tid >> 6;
@@ -58,7 +58,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, char* lds_
       voff = (uint32_t)(((k0 + krow) * ld + row0 + mc * 8) * 2);
     }
     char* dst = lds_tile + (i * 256 + wave * 64) * 16;  // wave-uniform; the DMA adds lane*16
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, 0, 0, AUX);
   }
 }
 
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   }
 
   if (nk > 0) {
-    stage_tile<TA>(rsA, lds, m0, kbeg, p.lda, tid);
-    stage_tile<TB>(rsB, lds + kTileBytes, n0, kbeg, p.ldb, tid);
+    stage_tile<TA, NB_AUX_A>(rsA, lds, m0, kbeg, p.lda, tid);
+    stage_tile<TB, NB_AUX_B>(rsB, lds + kTileBytes, n0, kbeg, p.ldb, tid);
   }
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
       if (kt + 1 < nk) {
         char* nxt = lds + ((kt + 1) & 1) * kStageBytes;
         const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
-        stage_tile<TA>(rsA, nxt, m0, k0, p.lda, tid);
-        stage_tile<TB>(rsB, nxt + kTileBytes, n0, k0, p.ldb, tid);
+        stage_tile<TA, NB_AUX_A>(rsA, nxt, m0, k0, p.lda, tid);
+        stage_tile<TB, NB_AUX_B>(rsB, nxt + kTileBytes, n0, k0, p.ldb, tid);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
       if (kt + 1 < nk) {
         char* nxt = lds + ((kt + 1) & 1) * kStageBytes;
         const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
-        stage_tile<TA>(rsA, nxt, m0, k0, p.lda, tid);
-        stage_tile<TB>(rsB, nxt + kTileBytes, n0, k0, p.ldb, tid);
+        stage_tile<TA, NB_AUX_A>(rsA, nxt, m0, k0, p.lda, tid);
+        stage_tile<TB, NB_AUX_B>(rsB, nxt + kTileBytes, n0, k0, p.ldb, tid);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {

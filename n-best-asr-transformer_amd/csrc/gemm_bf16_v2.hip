@@ -53,7 +53,7 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 }
 
 // one operand tile: ROWS x 32 bf16 = ROWS*4 16-byte chunks, 256 threads -> ROWS/64 DMA instructions per thread
-template <bool TR, int ROWS, int NT>
+template <bool TR, int ROWS, int NT, int AUX = 0>
 __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid) {
   const int wave = tid >> 6;
 #pragma unroll
@@ -70,7 +70,7 @@ __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* til
       const int mc = slot ^ (2 * (krow & 3) + 8 * ((krow >> 3) & 1));
       voff = (uint32_t)(((k0 + krow) * ld + row0 + mc * 8) * 2);
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, voff, 0, 0, AUX);
   }
 }
 
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
-        stage_tile2<TA, BM, NT>(rsA, lds + s0 * STAGE, m0, kbeg + (int64_t)s0 * BK, p.lda, tid);
-        stage_tile2<TB, BN, NT>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, p.ldb, tid);
+        stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0, kbeg + (int64_t)s0 * BK, p.lda, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, p.ldb, tid);
       }
     }
     {
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         int nb = buf + STAGES - 1;
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
-        stage_tile2<TA, BM, NT>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-        stage_tile2<TB, BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+        stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
       }
       const char* cur = lds + buf * STAGE;
       if ((DIAG & 2) == 0 || kt == 0) {
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
   for (int s = 0; s < STAGES; ++s) {
     if (s < nk) {
-      stage_tile2<TA, BM, NT>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
-      stage_tile2<TB, BN, NT>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
     }
   }
   bf16x8 afA[TMt], bfA[TNt], afB[TMt], bfB[TNt];
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     asm volatile("" ::: "memory");                                                                           \
     if (kt + STAGES < nk) {                                                                                  \
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES) * BK;                                                 \
-      stage_tile2<TA, BM, NT>(rsA, lds + buf * STAGE, m0, k0, p.lda, tid);                                       \
-      stage_tile2<TB, BN, NT>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, p.ldb, tid);                             \
+      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + buf * STAGE, m0, k0, p.lda, tid);                                       \
+      stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, p.ldb, tid);                             \
     }                                                                                                        \
     const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;                                                      \
     if (kt + 1 < nk) {                                                                                       \
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) {
     if (s < nk) {
-      stage_tile2<TA, BM, NT>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
-      stage_tile2<TB, BN, NT>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
     }
   }
   int buf = 0;
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       int nb = buf + STAGES - 1;
       if (nb >= STAGES) nb -= STAGES;
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
-      stage_tile2<TA, BM, NT>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-      stage_tile2<TB, BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
     }
     const char* cur = lds + buf * STAGE;
     bf16x8 af[TMt], bfr[TNt];
@@ -517,8 +517,8 @@ __global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
   };
   auto issue = [&](int gstage, int64_t m0, int64_t n0, int s) {   // stage s of the tile at (m0, n0) -> ring buffer gstage & 3
     char* dst = lds + (gstage & 3) * STAGE;
-    stage_tile2<false, BM, NT>(rsA, dst, m0, (int64_t)s * BK, p.lda, tid);
-    stage_tile2<false, BN, NT>(rsB, dst + A_BYTES, n0, (int64_t)s * BK, p.ldb, tid);
+    stage_tile2<false, BM, NT, NB_AUX_A>(rsA, dst, m0, (int64_t)s * BK, p.lda, tid);
+    stage_tile2<false, BN, NT, NB_AUX_B>(rsB, dst + A_BYTES, n0, (int64_t)s * BK, p.ldb, tid);
   };
 
   int t_cur = blockIdx.x;

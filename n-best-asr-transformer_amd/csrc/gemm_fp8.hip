@@ -56,7 +56,7 @@ __device__ __forceinline__ int xcd_remap8(int bid, int nwg) {
 }
 
 // one operand tile: ROWS rows x 64 bytes = 4 ROWS 16-byte chunks, NT threads -> 4 ROWS / NT LDS-DMA instructions per thread
-template <int ROWS = 256, int NT = 512>
+template <int ROWS = 256, int NT = 512, int AUX = 0>
 __device__ __forceinline__ void stage_tile8(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid) {
   const int wave = tid >> 6;
 #pragma unroll
@@ -65,7 +65,7 @@ __device__ __forceinline__ void stage_tile8(__amdgpu_buffer_rsrc_t rs, char* til
     const int row = p >> 2, slot = p & 3;
     const int kc = slot ^ ((row >> 2) & 3);
     const uint32_t voff = (uint32_t)((row0 + row) * ld + k0 + kc * 16);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, voff, 0, 0, AUX);
   }
 }
 
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
   #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
-        stage_tile8<BM, NT>(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
-        stage_tile8<BN, NT>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
+        stage_tile8<BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
+        stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
       }
     }
     {
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
         int nb = buf + STAGES - 1;
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = (int64_t)(kt + STAGES - 1) * BK8;
-        stage_tile8<BM, NT>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-        stage_tile8<BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+        stage_tile8<BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+        stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
       }
       const char* cur = lds + buf * STAGE;
   #pragma unroll
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
-        stage_tile8<BM, NT>(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
-        stage_tile8<BN, NT>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
+        stage_tile8<BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
+        stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
       }
     }
     int buf = 0;
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
         int nb = buf + STAGES - 1;
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = (int64_t)(kt + STAGES - 1) * BK8;
-        stage_tile8<BM, NT>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-        stage_tile8<BN, NT>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+        stage_tile8<BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
+        stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
       }
       const char* cur = lds + buf * STAGE;
 #pragma unroll
