@@ -56,23 +56,27 @@ from nbest_amd.optim import HipBertAdam
 from nbest_amd.trainer import GradReducer, broadcast_parameters, init_distributed, train_step
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, MI355X (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0       # dense fp8 MFMA peak (same guide); the fp8w mode's GEMMs are priced against this one
 
 
-def wgrad_traffic_from_profiles():
+def wgrad_traffic_from_profiles(fp8=False):
     """HBM bytes per weight-gradient launch (the GEMM plus its split-K reduce) from the newest tracked PMC table
     profiles/rNN_pmc.csv (tools/profile_step.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very
     command, gfx950 corrections applied by tools/pmc_table.py).  Returns (bytes or None, provenance string)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.csv")) if ("fp8w" in os.path.basename(f)) == fp8)
     if not files:
-        return None, "no profiles/r*_pmc.csv"
+        return None, "no profiles/r*_%spmc.csv" % ("fp8w_" if fp8 else "")
     total, launches = 0.0, 0.0
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
             k = row["kernel"]
-            is_gemm = ("gemm2_kernel" in k or "gemm_bf16_kernel" in k) and k.rstrip(">").endswith(", 6")   # EPI = F32_SPLITK
-            if not (is_gemm or "splitk_reduce" in k):
+            if fp8:
+                is_gemm = "gemm8tt_kernel" in k
+            else:
+                is_gemm = ("gemm2_kernel" in k or "gemm_bf16_kernel" in k) and k.rstrip(">").endswith(", 6")   # EPI = F32_SPLITK
+            if not (is_gemm or ("splitk_reduce8" in k if fp8 else ("splitk_reduce" in k and "reduce8" not in k))):
                 continue
             n, tb = float(row["launches_per_step"]), float(row["traffic_bytes_per_launch"])
             if tb != tb:
@@ -122,14 +126,14 @@ def cpu_baseline(labels, seconds_budget=25.0):
                 sample="%d steps of bert-base fp32 B=8 S=128 n_best=5 (fwd+loss+bwd+BertAdam), oracle on CPU" % n)
 
 
-def time_wgrad_in_step(model, step, B, S, n_steps=3):
+def time_wgrad_in_step(model, step, B, S, n_steps=3, operand_bytes=2.0):
     """The kernel with the largest share of the step (profiles/): the weight-gradient GEMM dW = dY^T . X over the
     M = B*S token rows (split-K, fp32 out), launched four times per layer (FFN-down, FFN-up, attention-out, QKV).
     Timed IN the training step, on the launch stream, with HIP events the library records around each of the 4 L
     launches (nbest_encoder_desc::wgrad_events; a launch = the GEMM kernel + its split-K reduce): `n_steps` further
     steps right after the timed region, same cache / clock / power state as the step itself.
-    Returns (avg ms per launch, avg algorithmic flops per launch, avg algorithmic bytes per launch = both bf16 operands
-    read once + the fp32 gradient written once)."""
+    Returns (avg ms per launch, avg algorithmic flops per launch, avg algorithmic bytes per launch = both operands (bf16, or
+    e4m3 in the fp8w mode: `operand_bytes`) read once + the fp32 gradient written once)."""
     import ctypes as C
     cfg = model.cfg
     H, F, L, M = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, B * S
@@ -153,7 +157,7 @@ def time_wgrad_in_step(model, step, B, S, n_steps=3):
         desc.wgrad_events, desc.wgrad_events_n = None, 0
     shapes = [(H, F), (F, H), (H, H), (3 * H, H)]
     flops = sum(2.0 * M * a * b for a, b in shapes) / 4
-    byts = sum(2.0 * M * (a + b) + 4.0 * a * b for a, b in shapes) / 4
+    byts = sum(operand_bytes * M * (a + b) + 4.0 * a * b for a, b in shapes) / 4
     return tot / n, flops, byts
 
 
@@ -262,27 +266,30 @@ def main():
                                    "fwd+losses+bwd+allreduce+BertAdam%s%s, dropout %s" % (
                                        cfg_label, {"bert": "bert-base-uncased", "xlm-roberta": "xlm-roberta-base"}.get(a.model, a.model), a.dtype,
                                        a.n_best, a.seq_len, a.batch, " + transcript pass and CLS-MSE (--add_l2_loss)" if a.add_l2_loss else "",
-                                       "; fp8w = forward and dgrad GEMMs on the block-scaled fp8 MFMA (e4m3 weight copy, e4m3 activation / "
-                                       "gradient copies), weight gradients and everything else bf16" if a.dtype == "fp8w" else "",
+                                       "; fp8w = forward, dgrad and weight-gradient GEMMs on the block-scaled fp8 MFMA (e4m3 weight copy, "
+                                       "e4m3 activation / gradient copies), everything else bf16, fp32 master weights" if a.dtype == "fp8w" else "",
                                        "off" if a.no_dropout else "on (0.1/0.1/0.3)"),
                        "global_batch": a.batch * world, "seq_len": a.seq_len, "n_best": a.n_best, "parallelism": "dp%d" % world,
                        "add_l2_loss": bool(a.add_l2_loss)},
             "flops_per_utterance": fpu,
-            "step_mfma_frac": round(utt * fpu / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+            "step_mfma_frac": round(utt * fpu / 1e12 / ((PEAK_FP8_TFLOPS if a.dtype == "fp8w" else PEAK_BF16_TFLOPS) * world), 4),
             "last_loss_per_utt": round(loss / a.batch, 4),
         }
         if a.dtype in ("bf16", "fp8w") and not a.no_roofline:
-            ms, fl, by = time_wgrad_in_step(model, step, a.batch, a.seq_len)
+            f8 = a.dtype == "fp8w"
+            peak = PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS
+            ms, fl, by = time_wgrad_in_step(model, step, a.batch, a.seq_len, operand_bytes=1.0 if f8 else 2.0)
             ach = fl / (ms * 1e-3) / 1e12
-            traffic, src = wgrad_traffic_from_profiles() if (a.model == "bert" and a.batch == 256 and a.seq_len == 128) else (None, "not measured for this shape")
+            traffic, src = wgrad_traffic_from_profiles(f8) if (a.model == "bert" and a.batch == 256 and a.seq_len == 128) else (None, "not measured for this shape")
             H_, F_ = cfg.hidden_size, cfg.intermediate_size
-            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+            kern = ("gemm8tt_kernel (e4m3 x e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, ds_read_b64_tr_b8 transposed reads) + splitk_reduce8_kernel" if f8 else
+                    "gemm2_kernel<256,256,...,true,true,F32_SPLITK> for QKV/FFN, gemm_bf16_kernel<true,true,F32_SPLITK> for the attention "
+                    "output, each followed by its split-K reduce")
+            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
                                "kernel": "weight-gradient GEMM dW = dY^T.X (both operands token-major, transposed LDS reads, split-K, fp32 "
-                                         "out; gemm2_kernel<256,256,...,true,true,F32_SPLITK> for QKV/FFN, gemm_bf16_kernel<true,true,"
-                                         "F32_SPLITK> for the attention output, each followed by its split-K reduce), K = %d token rows; "
-                                         "avg over the 4 launches of a layer: %dx%d, %dx%d, %dx%d, %dx%d" % (
-                                             a.batch * a.seq_len, H_, F_, F_, H_, H_, H_, 3 * H_, H_),
+                                         "out; %s), K = %d token rows; avg over the 4 launches of a layer: %dx%d, %dx%d, %dx%d, %dx%d" % (
+                                             kern, a.batch * a.seq_len, H_, F_, F_, H_, H_, H_, 3 * H_, H_),
                                "timing": "HIP events recorded by the library around each of the %d launches per step, on the launch "
                                          "stream, inside 3 training steps run right after the timed region" % (4 * cfg.num_hidden_layers),
                                "avg_launch_ms": round(ms, 4), "flops_per_launch": fl, "algorithmic_bytes_per_launch": by}

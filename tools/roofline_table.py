@@ -11,6 +11,7 @@ import sys
 
 M, H, F, B, S, HEADS, L = 32768, 768, 3072, 256, 128, 12, 12
 PEAK_TF, PEAK_TB = 2500.0, 8.0
+PEAK_TF8 = 5000.0          # dense fp8 MFMA: the rows of the fp8w mode's GEMMs (marked "fp8") are priced against it
 
 
 def gf(m, n, k):
@@ -20,6 +21,21 @@ def gf(m, n, k):
 # (substring of the kernel name, grid size or None) -> (label, GFLOP per launch or None, algorithmic MB per launch)
 # for kernels that serve two shapes through one (name, grid) the figures are the per-launch average
 KERNELS = [
+    # ---- fp8w mode (profiles/rNN_fp8w_pmc.csv): e4m3 operands, 1 byte each ----
+    ("gemm8tt_kernel", 129024, "fp8 weight gradient FFN-up / FFN-down (3072x768 | 768x3072, K = 32 768)", gf(F, H, M), (M * (F + H) + F * H * 4) / 1e6),
+    ("gemm8tt_kernel", 124416, "fp8 weight gradient QKV (2304x768) | attention-out (768x768)", (gf(3 * H, H, M) + gf(H, H, M)) / 2, (M * (4 * H + 2 * H) / 2 + (3 * H * H + H * H) / 2 * 4) / 1e6),
+    ("gemm8_kernel<5, 4>", None, "fp8 dgrad + residual: QKV (K 2304) | FFN-up (K 3072), N 768", (gf(M, H, 3 * H) + gf(M, H, F)) / 2, (M * (3 * H + F) / 2 + 2 * M * H * 2 + (3 * H + F) / 2 * H) / 1e6),
+    ("gemm8_kernel<2, 4>", None, "fp8 forward FFN-up + bias + GELU (writes GELU' 8-bit and e4m3 GELU)", gf(M, F, H), (M * H + 2 * M * F + F * H) / 1e6),
+    ("gemm8_kernel<4, 4>", None, "fp8 dgrad FFN-down x GELU' (+ fused db1; e4m3 output only)", gf(M, F, H), (M * H + 2 * M * F + F * H) / 1e6),
+    ("gemm8_kernel<3, 4>", None, "fp8 forward FFN-down + bias + dropout + residual", gf(M, H, F), (M * F + 2 * M * H * 2 + F * H) / 1e6),
+    ("gemm8_kernel<3, 2>", None, "fp8 forward attention-out + bias + dropout + residual (256x128 tiles)", gf(M, H, H), (M * H + 2 * M * H * 2 + H * H) / 1e6),
+    ("gemm8_kernel<1, 4>", None, "fp8 forward QKV + bias", gf(M, 3 * H, H), (M * H + M * 3 * H * 2 + 3 * H * H) / 1e6),
+    ("gemm8_kernel<0, 2>", None, "fp8 dgrad attention-out (256x128 tiles)", gf(M, H, H), (M * H + M * H * 2 + H * H) / 1e6),
+    ("splitk_reduce8_kernel", None, "split-K reduce of an fp8 weight gradient", None, None),
+    ("quant_w8t_kernel", None, "e4m3 transposed weight copy (from the fp32 master)", None, 85e6 * 5 / 1e6),
+    ("quant_w8_kernel", None, "e4m3 weight copy (from the fp32 master)", None, 85e6 * 5 / 1e6),
+    ("absmax_kernel", None, "per-matrix max |w| (weight scales)", None, 85e6 * 4 / 1e6),
+    # ---- bf16 ----
     ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 129024, "weight gradient FFN-up / FFN-down (3072x768 | 768x3072, K = 32 768)", gf(F, H, M), (M * (F + H) * 2 + F * H * 4) / 1e6),
     ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 124416, "weight gradient QKV (2304x768)", gf(3 * H, H, M), (M * 4 * H * 2 + 3 * H * H * 4) / 1e6),
     ("gemm_bf16_kernel<true, true, 6>", None, "weight gradient attention-out (768x768)", gf(H, H, M), (M * 2 * H * 2 + H * H * 4) / 1e6),
@@ -67,7 +83,8 @@ def main(path):
         if flops:
             ach = flops / us * 1e-3        # GF / µs = PF... -> TFLOP/s = GF / (µs * 1e-6) / 1e3
             ach = flops / (us * 1e-6) / 1e3
-            alg, a, f = "%.1f GFLOP" % flops, "%.0f TFLOP/s" % ach, "%.1f %% (MFMA)" % (100 * ach / PEAK_TF)
+            pk = PEAK_TF8 if label.startswith("fp8 ") else PEAK_TF
+            alg, a, f = "%.1f GFLOP" % flops, "%.0f TFLOP/s" % ach, "%.1f %% (%sMFMA)" % (100 * ach / pk, "fp8 " if pk == PEAK_TF8 else "")
         elif mb:
             tb = mb / us / 1e6 * 1e6 / 1e6  # MB / µs = TB/s
             tb = mb / us
