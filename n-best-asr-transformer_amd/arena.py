@@ -107,6 +107,8 @@ class ParamArena:
         # transposed bf16 copy of the per-layer weight matrices (same offsets): the dgrad GEMMs read it so both of
         # their operands are k-contiguous.  Only allocated on a GPU (the kernel that fills it is HIP).
         self.w16t = None
+        self.lazy_w16t = False      # set by the model while its backward runs in fp8: the bf16 transposed copy has no reader then
+        self.w16t_stale = False
         self.w8 = self.w8t = self.w8_inv_scale = self._w8_ws = self.gamax = None
         self._tdescs = None
         if self.w16 is not None and self.device.type == "cuda":
@@ -150,14 +152,21 @@ class ParamArena:
         """the derived copies of the weight matrices the next step reads: k-contiguous bf16 copy for the dgrads and, with
         the fp8 forward enabled, the e4m3 copy + per-matrix scales (called after every optimizer step)"""
         if self.w16t is not None:
-            d, n, t = self._tdescs
-            hb.check(hb.lib().nbest_transpose_weights(hb.ptr(self.w16), hb.ptr(self.w16t), hb.ptr(d), n, t, hb.stream_ptr()),
-                     "transpose_weights")
+            if self.lazy_w16t:
+                self.w16t_stale = True          # model._backward_pass refreshes it should a bf16 backward run after all
+            else:
+                self.refresh_w16t()
         if self.w8 is not None:
             d, n, t = self._tdescs
             hb.check(hb.lib().nbest_quantize_weights_fp8(hb.ptr(self.p), hb.ptr(self.w8), hb.ptr(self.w8t), hb.ptr(d), n, t,
                                                          hb.ptr(self.w8_inv_scale), hb.ptr(self._w8_ws), self._w8_ws.numel(),
                                                          hb.stream_ptr()), "quantize_weights_fp8")
+
+    def refresh_w16t(self):
+        d, n, t = self._tdescs
+        hb.check(hb.lib().nbest_transpose_weights(hb.ptr(self.w16), hb.ptr(self.w16t), hb.ptr(d), n, t, hb.stream_ptr()),
+                 "transpose_weights")
+        self.w16t_stale = False
 
     def enable_fp8_forward(self):
         """allocate the e4m3 weight copy (one byte per element at the arena's element offsets) and its per-matrix inverse

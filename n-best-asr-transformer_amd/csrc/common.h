@@ -130,6 +130,32 @@ inline bool nb_stream_output(int64_t out_bytes) {
   return out_bytes >= (min_mb << 20);
 }
 
+// ---- 64x64 tile transpose of a row-major matrix with 1- or 2-byte elements (transposed weight copies) ----------------------
+// 256 threads; 16-byte global loads and stores, the transposition happens in the LDS image (element-wise writes into
+// tile[col][row], 16-byte reads of a transposed row).  For a tile fully inside a matrix whose dimensions and base are multiples
+// of 16 elements; the callers keep an element-wise path for everything else.  `tile`: 64 x (64 + 16 / sizeof(T)) elements.
+template <typename T>
+__device__ __forceinline__ void transpose_tile64(const T* __restrict__ s, T* __restrict__ o, int rows, int cols, int r0, int c0,
+                                                 T* tile) {
+  constexpr int EPV = 16 / (int)sizeof(T);         // elements per 16-byte vector: 16 (e4m3) or 8 (bf16)
+  constexpr int PITCH = 64 + EPV;
+  constexpr int CPR = 64 / EPV;                    // vectors per tile row
+  typedef __attribute__((ext_vector_type(EPV))) T vec_t;
+#pragma unroll
+  for (int it = 0; it < (64 * CPR) / 256; ++it) {
+    const int idx = it * 256 + threadIdx.x, r = idx / CPR, ch = idx % CPR;
+    const vec_t v = *(const vec_t*)(s + (int64_t)(r0 + r) * cols + c0 + ch * EPV);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) tile[(ch * EPV + e) * PITCH + r] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < (64 * CPR) / 256; ++it) {
+    const int idx = it * 256 + threadIdx.x, c = idx / CPR, ch = idx % CPR;
+    *(vec_t*)(o + (int64_t)(c0 + c) * rows + r0 + ch * EPV) = *(const vec_t*)(tile + c * PITCH + ch * EPV);
+  }
+}
+
 // ---- wave64 / block reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

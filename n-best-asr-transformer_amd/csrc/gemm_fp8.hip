@@ -404,10 +404,12 @@ __global__ __launch_bounds__(256) void quant_w8_kernel(const float* __restrict__
 
 // the same quantisation, written TRANSPOSED ([cols][rows] at the matrix' offset): the k-contiguous B operand of the dgrads.
 // One launch: block -> (matrix, 64x64 tile) through descs[].tile_start, as transpose_multi_kernel.
-__global__ __launch_bounds__(256) void quant_w8t_kernel(const float* __restrict__ w, uint8_t* __restrict__ w8t,
+// (w8 != nullptr: the transposed copy is made from the already quantised bytes - a quarter of the master's traffic)
+__global__ __launch_bounds__(256) void quant_w8t_kernel(const float* __restrict__ w, const uint8_t* __restrict__ w8,
+                                                        uint8_t* __restrict__ w8t,
                                                         const nbest_matrix_desc* __restrict__ descs, int n,
                                                         const uint32_t* __restrict__ amax_bits) {
-  __shared__ uint8_t tile[64][68];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[64][80];
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -420,6 +422,10 @@ __global__ __launch_bounds__(256) void quant_w8t_kernel(const float* __restrict_
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const float* src = w + d.offset;
   uint8_t* o = w8t + d.offset;
+  if (w8 && r0 + 64 <= d.rows && c0 + 64 <= d.cols && ((d.rows | d.cols | d.offset) & 15) == 0) {   // 16-byte path (every encoder matrix)
+    transpose_tile64<uint8_t>(w8 + d.offset, o, d.rows, d.cols, r0, c0, &tile[0][0]);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = r0 + ty + 4 * i, c = c0 + tx;
@@ -721,7 +727,7 @@ extern "C" int nbest_quantize_weights_fp8(const float* master, void* w8, void* w
   NB_LAUNCH_CHECK();
   if (w8t) {
     NB_CHECK(n_tiles > 0, NBEST_ERR_ARG, "quantize_weights_fp8: n_tiles");
-    quant_w8t_kernel<<<n_tiles, 256, 0, st>>>(master, (uint8_t*)w8t, descs, n_matrices, (const uint32_t*)ws);
+    quant_w8t_kernel<<<n_tiles, 256, 0, st>>>(master, (const uint8_t*)w8, (uint8_t*)w8t, descs, n_matrices, (const uint32_t*)ws);
     NB_LAUNCH_CHECK();
   }
   return NBEST_OK;

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
 // arenas (the k-contiguous weight copy the dgrad GEMMs read).  One launch: block -> (matrix, 64x64 tile).
 __global__ __launch_bounds__(256) void transpose_multi_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
                                                               const nbest_matrix_desc* __restrict__ descs, int n) {
-  __shared__ bf16 tile[64][66];
+  __shared__ __attribute__((aligned(16))) bf16 tile[64][72];
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const bf16* __rest
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const bf16* s = src + d.offset;
   bf16* o = dst + d.offset;
+  if (r0 + 64 <= d.rows && c0 + 64 <= d.cols && ((d.rows | d.cols | d.offset) & 7) == 0) {   // 16-byte path (every encoder matrix)
+    transpose_tile64<bf16>(s, o, d.rows, d.cols, r0, c0, &tile[0][0]);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = r0 + ty + 4 * i, c = c0 + tx;

@@ -13,6 +13,7 @@ Training does not go through torch autograd: ``forward_backward`` enqueues the w
 gradients in the flat arena ``arena.g`` (also visible as ``param.grad`` views).
 """
 import ctypes as C
+import os
 import types
 
 import torch
@@ -230,10 +231,13 @@ class NBestSTCModel(nn.Module):
             d.w8t = a.w8t.data_ptr()
             d.gamax_prev, d.gamax_new = a.gamax[self._gamax_gen].data_ptr(), a.gamax[1 - self._gamax_gen].data_ptr()
             d.fp8_bwd = int(self._gamax_valid)
+            a.lazy_w16t = self._gamax_valid       # steady state: every dgrad reads w8t, nobody reads the bf16 transposed copy
 
     def _backward_pass(self, ps, dcls, accumulate, chunks=None, on_chunk_done=None):
         cfg = self.cfg
         self._set_fp8_backward(ps.desc)
+        if self.arena.w16t_stale and not (self.fp8_backward and self._gamax_valid):
+            self.arena.refresh_w16t()             # a bf16 backward after fp8 steps (history dropped, mode switched)
         dh = hb.cls_grad_scatter(dcls, ps.B, ps.S, cfg.hidden_size, self.compute_dtype)
         ids, seg, pos, mask = ps.inputs
         L = cfg.num_hidden_layers

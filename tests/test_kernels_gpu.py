@@ -428,3 +428,39 @@ def test_wgrad_fp8_transposed_reads(M, N, K):
     amax = torch.tensor([3.0], device=DEV).view(torch.int32)             # scale 2^floor(log2(224/3)) = 64
     got2 = hb.wgrad_fp8(dY8.view(torch.uint8), X8.view(torch.uint8), M, N, K, a_amax=amax, out=got.clone(), accumulate=True)
     close("wgrad_fp8 scaled + accumulate", got2, ref * (1 + 1 / 64.0), 1e-4)
+
+
+def test_transposed_weight_copies():
+    """k-contiguous copies of the weight matrices for the dgrad GEMMs: bf16 transpose (nbest_transpose_weights) and e4m3 copy +
+    its transpose (nbest_quantize_weights_fp8), on matrices that take the 16-byte tile path (dimensions multiples of 64) and on
+    ones that take the element-wise path (ragged) - bit-exact against torch."""
+    import ctypes as C
+    shapes = [(128, 192), (100, 72), (64, 256), (70, 64)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += (r * c + 63) // 64 * 64
+    g = torch.Generator().manual_seed(7)
+    master = torch.randn(total, generator=g).to(DEV)
+    arr = (hb.MatrixDesc * len(shapes))()
+    t = 0
+    for i, ((r, c), off) in enumerate(zip(shapes, offs)):
+        arr[i].offset, arr[i].rows, arr[i].cols, arr[i].tile_start = off, r, c, t
+        t += ((r + 63) // 64) * ((c + 63) // 64)
+    descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    w16 = master.bfloat16()
+    w16t = torch.zeros_like(w16)
+    hb.check(hb.lib().nbest_transpose_weights(hb.ptr(w16), hb.ptr(w16t), hb.ptr(descs), len(shapes), t, hb.stream_ptr()), "transpose_weights")
+    w8, w8t = torch.zeros(total, dtype=torch.uint8, device=DEV), torch.zeros(total, dtype=torch.uint8, device=DEV)
+    inv = torch.zeros(len(shapes), device=DEV)
+    ws = torch.zeros(4 * len(shapes) + 16, dtype=torch.uint8, device=DEV)
+    hb.check(hb.lib().nbest_quantize_weights_fp8(hb.ptr(master), hb.ptr(w8), hb.ptr(w8t), hb.ptr(descs), len(shapes), t, hb.ptr(inv),
+                                                 hb.ptr(ws), ws.numel(), hb.stream_ptr()), "quantize_weights_fp8")
+    for i, ((r, c), off) in enumerate(zip(shapes, offs)):
+        m = master[off:off + r * c].view(r, c)
+        assert torch.equal(w16t[off:off + r * c].view(c, r), m.bfloat16().t()), shapes[i]
+        s = 2.0 ** math.floor(math.log2(224.0 / m.abs().max().item()))
+        assert abs(inv[i].item() * s - 1.0) < 1e-6
+        q = _e4m3((m * s).cpu()).view(torch.uint8).to(DEV)
+        assert torch.equal(w8[off:off + r * c].view(r, c), q), shapes[i]
+        assert torch.equal(w8t[off:off + r * c].view(c, r), q.t()), shapes[i]
