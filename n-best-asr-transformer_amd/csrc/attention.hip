@@ -175,8 +175,9 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int s) {
 // write a wave's [32][64] fp32 accumulator pair (columns 0-31 / 32-63; lane = column) into rows
 // row0.. of a plain [rows][64] bf16 LDS image, then store those 32 rows with 16-byte accesses.
 __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0, const f32x16& o1, int lane, bf16* gbase,
-                                           int64_t gld, int rows_valid, uint8_t* g8 = nullptr, float s8 = 1.f,
-                                           float* amax = nullptr) {   // g8: optional e4m3 copy of (tile * s8); amax: running max |tile|
+                                           int64_t gld, int rows_valid, uint8_t* g8, float s8, float& amax,
+                                           bool want_amax) {   // g8: optional e4m3 copy of (tile * s8); amax: running max |tile|
+  // (amax by reference + flag: as an optional POINTER to a local it was address-taken and lived in scratch memory)
   const int hh = lane >> 5, c = lane & 31;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -191,14 +192,14 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
     if (row < rows_valid) {
       const i32x4 v = *(const i32x4*)(img + (row0 + row) * 128 + ch * 16);
       if (gbase) *(i32x4*)(gbase + (int64_t)row * gld + ch * 8) = v;   // (null: only the e4m3 copy is wanted)
-      if (g8 || amax) {
+      if (g8 || want_amax) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, v);
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = (float)b[e];
-        if (amax) {
+        if (want_amax) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) *amax = fmaxf(*amax, fabsf(f[e]));
+          for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
         }
         if (g8) {
 #pragma unroll
@@ -208,6 +209,12 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
       }
     }
   }
+}
+
+__device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0, const f32x16& o1, int lane, bf16* gbase,
+                                           int64_t gld, int rows_valid, uint8_t* g8 = nullptr, float s8 = 1.f) {
+  float unused = 0.f;
+  store_tile(img, row0, o0, o1, lane, gbase, gld, rows_valid, g8, s8, unused, false);
 }
 
 template <int NKB>
@@ -634,10 +641,10 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
     uint8_t* g8 = f8.out8 ? f8.out8 + goff : nullptr;
     const float s8 = fp8_grad_scale(f8.amax_prev);
     float amax8 = 0.f;
-    float* am = f8.amax_new ? &amax8 : nullptr;
-    store_tile(Qt, r0, dq0, dq1, lane, g, ld, S - r0, g8, s8, am);
-    store_tile(Kt, r0, dk0, dk1, lane, g ? g + H : nullptr, ld, S - r0, g8 ? g8 + H : nullptr, s8, am);
-    store_tile(dOt, r0, dv0, dv1, lane, g ? g + 2 * H : nullptr, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, am);
+    const bool am = f8.amax_new != nullptr;
+    store_tile(Qt, r0, dq0, dq1, lane, g, ld, S - r0, g8, s8, amax8, am);
+    store_tile(Kt, r0, dk0, dk1, lane, g ? g + H : nullptr, ld, S - r0, g8 ? g8 + H : nullptr, s8, amax8, am);
+    store_tile(dOt, r0, dv0, dv1, lane, g ? g + 2 * H : nullptr, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, amax8, am);
     if (f8.amax_new) {
       amax8 = wave_max(amax8);
       if (lane == 0) amax_update(f8.amax_new, amax8);
@@ -787,7 +794,7 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
   constexpr int NW = 8, NT = 512, KH = 256, RS = 512;
   const float s8 = fp8_grad_scale(f8.amax_prev);
   float amax8 = 0.f;
-  float* am = f8.amax_new ? &amax8 : nullptr;   // keys per half; dS slab row stride (256 keys x 2 B)
+  const bool am = f8.amax_new != nullptr;       // keys per half; dS slab row stride (256 keys x 2 B)
   const int Sp = nkb * 32;
   char* Qs = lds;                                       // [2][32][128 B]
   char* dOs = Qs + 2 * 4096;                            // [2][32][128 B]
@@ -924,8 +931,8 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
       const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
       bf16* g = dqkv ? dqkv + goff : nullptr;
       uint8_t* g8 = f8.out8 ? f8.out8 + goff : nullptr;
-      store_tile(Kt + wave * 4096, 0, dk0, dk1, lane, g ? g + H : nullptr, ld, S - r0, g8 ? g8 + H : nullptr, s8, am);
-      store_tile(Kt + wave * 4096, 0, dv0, dv1, lane, g ? g + 2 * H : nullptr, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, am);
+      store_tile(Kt + wave * 4096, 0, dk0, dk1, lane, g ? g + H : nullptr, ld, S - r0, g8 ? g8 + H : nullptr, s8, amax8, am);
+      store_tile(Kt + wave * 4096, 0, dv0, dv1, lane, g ? g + 2 * H : nullptr, ld, S - r0, g8 ? g8 + 2 * H : nullptr, s8, amax8, am);
     }
   }
   __syncthreads();
@@ -954,12 +961,12 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
   if (wave < nkb) {
     const int r0 = 32 * wave;
     const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
-    store_tile(Kt + wave * 4096, 0, dqa0, dqa1, lane, dqkv ? dqkv + goff : nullptr, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, am);
+    store_tile(Kt + wave * 4096, 0, dqa0, dqa1, lane, dqkv ? dqkv + goff : nullptr, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, amax8, am);
   }
   if (wave + 8 < nkb) {
     const int r0 = 32 * (wave + 8);
     const int64_t goff = ((int64_t)b * S + r0) * ld + h * 64;
-    store_tile(Kt + wave * 4096, 0, dqb0, dqb1, lane, dqkv ? dqkv + goff : nullptr, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, am);
+    store_tile(Kt + wave * 4096, 0, dqb0, dqb1, lane, dqkv ? dqkv + goff : nullptr, ld, S - r0, f8.out8 ? f8.out8 + goff : nullptr, s8, amax8, am);
   }
   if (f8.amax_new) {
     amax8 = wave_max(amax8);
