@@ -105,6 +105,29 @@ template <> struct Vec8<bf16> {
 #define NB_AUX_B ((NBEST_DIAG & 16384) ? 2 : 0)
 #endif
 
+// Tile id -> (tile_m, tile_n) with the tile columns blocked in groups of `gn`: every tile row of one column group is visited
+// before the next group, so the group's slice of the WEIGHT operand ([gn * BN][K]) stays in the 4 MiB L2 of the XCD while the
+// activation panel streams past it.  Row-major order (gn = tiles_n) re-reads the whole weight matrix once per tile row, and
+// a 3072 x 768 bf16 matrix (4.7 MB) does not fit the L2: the PMC counters showed 140-230 MB of such re-reads per GEMM.
+__device__ __forceinline__ void nb_tile_coords(int t, int tiles_m, int gn, int& tm, int& tn) {
+  const int per_group = tiles_m * gn;
+  const int g = t / per_group, r = t - g * per_group;
+  tm = r / gn;
+  tn = g * gn + (r - tm * gn);
+}
+// host: the largest divisor of tiles_n whose weight slice (cols_per_tile * K * elem_bytes each) stays under `limit_kb`.  Measured
+// on the step (same-box A/B): bf16 - halves of the 4.7 MB FFN matrices and thirds of the 3.5 MB QKV matrix pay (limit 2400),
+// finer groups do not (every extra group re-reads the activations); fp8 - 1.2 MB slices (limit 1600) beat the whole 2.4 MB matrix.
+inline int nb_group_cols(int64_t tiles_n, int64_t slice_bytes_per_tile, int64_t limit_kb) {
+  int best = 1;
+  for (int d = 1; d <= tiles_n; ++d)
+    if (tiles_n % d == 0 && d * slice_bytes_per_tile <= limit_kb * 1024) best = d;
+#ifdef NBEST_EXPERIMENTS
+  if (const char* e = getenv("NBEST_GN")) { const int v = atoi(e); if (v > 0 && tiles_n % v == 0) best = v; else if (v == 0) best = (int)tiles_n; }
+#endif
+  return best;
+}
+
 // Streaming (nontemporal) store: for GEMM / attention outputs of tens to hundreds of MB, which otherwise wash the operands
 // other tiles still read out of the 4 MiB L2 of every XCD.
 // (inline asm: written as `nt ? __builtin_nontemporal_store : plain store` the optimiser merges the two stores of the diamond

@@ -32,6 +32,7 @@ struct GemmP {
   uint32_t a_bytes, b_bytes;
   DropCfg drop;
   int stream_out;     // epilogue stores are nontemporal (common.h st_stream)
+  int gn;             // tile columns per L2 group (common.h nb_tile_coords)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmP p) {
   const int id = xcd_remap(blockIdx.x, nwg);
   const int tiles = p.tiles_m * p.tiles_n;
   const int z = id / tiles, t = id - z * tiles;
-  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  nb_tile_coords(t, p.tiles_m, p.gn, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
   const int64_t kbeg = (int64_t)z * p.k_per_split;
   const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
@@ -383,6 +385,7 @@ int nbest_gemm_bf16(const nbest_gemm_args* a, hipStream_t st) {
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
   p.stream_out = nb_stream_output(a->M * a->N * 2) ? 1 : 0;
+  p.gn = (int)(a->N / BN);      // row-major tile order (column groups measured neutral to negative on the N = 768 shapes this kernel serves)
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm(bf16): dropout counter overflow");
   const int epi = a->epilogue;
   if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)

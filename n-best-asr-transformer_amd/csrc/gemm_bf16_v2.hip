@@ -45,6 +45,7 @@ struct GemmP2 {
   uint32_t a_bytes, b_bytes;
   DropCfg drop;
   int stream_out;     // epilogue stores are nontemporal (common.h st_stream)
+  int gn;             // tile columns per L2 group (common.h nb_tile_coords)
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   const int id = xcd_remap2(blockIdx.x, nwg);
   const int tiles = p.tiles_m * p.tiles_n;
   const int z = id / tiles, t = id - z * tiles;
-  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  nb_tile_coords(t, p.tiles_m, p.gn, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
   const int64_t kbeg = (int64_t)z * p.k_per_split;
   const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
@@ -806,6 +808,8 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
   p.stream_out = nb_stream_output(a->M * a->N * 2) ? 1 : 0;
+  // B is a weight matrix (k-contiguous [N][K]) in the forward / dgrad GEMMs; the weight gradients have no small operand
+  p.gn = (!a->trans_a && !a->trans_b) ? nb_group_cols(a->N / pl.bn, (int64_t)pl.bn * a->K * 2, 2400) : (int)(a->N / pl.bn);
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm(bf16): dropout counter overflow");
   const int epi = a->epilogue;
   if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)

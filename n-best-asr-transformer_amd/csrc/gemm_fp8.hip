@@ -44,6 +44,7 @@ struct GemmP8 {
   float* colpart;              // DGELU: fused column sums of the output (bias gradient), partial rows [tiles_m * 2][N]
   DropCfg drop;
   int stream_out;
+  int gn;                      // tile columns per L2 group (common.h nb_tile_coords)
 };
 
 #ifdef NBEST_EXPERIMENTS
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int id = xcd_remap8(blockIdx.x, gridDim.x);
-  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  nb_tile_coords(id, p.tiles_m, p.gn, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
   const int nk = (DIAG8 & 2048) ? 1 : (int)(p.K / BK8);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
@@ -791,6 +793,7 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
   p.colpart = (epi == NBEST_EPI_DGELU && a->colsum_out) ? (float*)a->ws : nullptr;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
   p.stream_out = nb_stream_output(a->M * a->N * 2) ? 1 : 0;
+  p.gn = nb_group_cols(p.tiles_n, (int64_t)64 * wn * a->K, 1600);
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm_fp8: dropout counter overflow");
 
   const int grid = p.tiles_m * p.tiles_n;
