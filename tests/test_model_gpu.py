@@ -318,9 +318,10 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False, fp8_bwd=False):
 @pytest.mark.parametrize("bwd8", [False, True])
 @pytest.mark.parametrize("family,B,S,St", [("bert", 3, 40, 12), ("bert", 2, 200, 40), ("xlmr-large", 2, 72, 24), ("bert", 2, 300, 40)])
 def test_fp8_forward_matches_its_oracle_leg(family, B, S, St, bwd8, labels):
-    """"fp8w" (BASELINE configs[4]: fp8 weights on the CDNA4 fp8 MFMA): forward GEMMs - and with ``bwd8`` the dgrad GEMMs - on
-    v_mfma_scale_f32_32x32x64_f8f6f4 from a per-matrix-scaled e4m3 copy of the weights; activations are cast to e4m3 (unit scale)
-    by their producers, gradient operands to e4m3 with a per-tensor delayed scale; weight gradients, attention, LayerNorm,
+    """"fp8w" (BASELINE configs[4]: fp8 weights on the CDNA4 fp8 MFMA): forward GEMMs - and with ``bwd8`` the dgrad AND weight-gradient
+    GEMMs - on v_mfma_scale_f32_32x32x64_f8f6f4 from a per-matrix-scaled e4m3 copy of the weights; activations are cast to e4m3 (unit
+    scale) by their producers, gradient operands to e4m3 with a per-tensor delayed scale (one scaled copy feeds the dgrad and the
+    wgrad; the run has a transcript pass, so the second pass ACCUMULATES into the first one's weight gradients); attention, LayerNorm,
     heads and the optimizer are the bf16 path.  Bar: the same as for bf16 - within 1.5 x the noise floor of the oracle leg that
     rounds exactly the same tensors (oracle/bf16sim.py, fp8=True[, fp8_bwd=True]): scores, loss, per-tensor gradient noise-to-signal."""
     import nbest_amd  # noqa: F401
