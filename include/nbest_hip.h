@@ -118,9 +118,10 @@ int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream);
  * C[M][N] (bf16) = epi((A8[M][K] . W8[N][K]^T) * out_scale + bias): both operands OCP e4m3 (one byte per element, k-contiguous),
  * on the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; out_scale = 1 / (per-matrix weight scale).
  * Replaces the same nn.Linear forwards as nbest_gemm (installed modeling_bert.py:154-177, 282-293, 325-351); the
- * weight gradients stay on the bf16 kernels.  Forward epilogues: NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU (writes C = gelu bf16,
- * U = gelu' 8-bit, C8 = e4m3 copy of gelu for the next GEMM), NBEST_EPI_BIAS_DROP_RES; dgrad epilogues (B = the TRANSPOSED e4m3
- * weight copy, A = e4m3 gradient copy): NBEST_EPI_NONE, NBEST_EPI_RES, NBEST_EPI_DGELU.  N % 256 == 0, K % 64 == 0.            */
+ * weight gradients have their own entry point (nbest_wgrad_fp8 below).  Forward epilogues: NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU
+ * (writes C = gelu bf16, U = gelu' 8-bit, C8 = e4m3 copy of gelu for the next GEMM), NBEST_EPI_BIAS_DROP_RES; dgrad epilogues
+ * (B = the TRANSPOSED e4m3 weight copy, A = e4m3 gradient copy): NBEST_EPI_NONE, NBEST_EPI_RES, NBEST_EPI_DGELU.
+ * N % 256 == 0, K % 64 == 0.  C may be NULL for BIAS_GELU / DGELU when C8 is given (every reader takes the e4m3 copy).          */
 typedef struct nbest_gemm_fp8_args {
   const void* A;      /* e4m3 [M][lda] */
   const void* B;      /* e4m3 [N][ldb] (the weight matrix as stored, [out][in]) */

@@ -1,4 +1,5 @@
-// K2/K4/K6 in fp8: forward GEMMs C = epi((A8 . W8^T) * out_scale) with BOTH operands in OCP e4m3, on the block-scaled
+// K2/K4/K6 in fp8: forward / dgrad GEMMs C = epi((A8 . W8^T) * out_scale) (gemm8_kernel) and weight gradients dW = dY8^T . X8
+// (gemm8tt_kernel, second half of the file) with BOTH operands in OCP e4m3, on the block-scaled
 // matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; the per-tensor weight scale is applied to the
 // fp32 accumulator in the epilogue).  On gfx950 the non-scaled fp8 MFMA runs at the bf16 rate; this one sustains
 // 4.3 PFLOP/s in a register-only loop with random operands against 2.1 for v_mfma_f32_16x16x32_bf16
@@ -14,8 +15,9 @@
 //             of the bank row, and within a group their r >> 2 are {0,3,5,6} or {1,2,4,7}: distinct in the low two bits;
 //   C/D: with the operands swapped (B first) lane l owns output row (l & 31) and the columns
 //        (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the 32-column block: four groups of 4 consecutive columns.
-// Epilogues: NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU (writes gelu bf16, gelu' 8-bit AND the fp8 copy of gelu the next GEMM
-// reads), NBEST_EPI_BIAS_DROP_RES.  Outputs are bf16: everything downstream (attention, LayerNorm, backward) is the bf16 path.
+// Epilogues: forward NBEST_EPI_BIAS, NBEST_EPI_BIAS_GELU (gelu' 8-bit + the e4m3 copy of gelu the next GEMM reads; bf16 gelu only on
+// request), NBEST_EPI_BIAS_DROP_RES; dgrad NBEST_EPI_NONE, NBEST_EPI_RES, NBEST_EPI_DGELU (x gelu', scaled e4m3 copy, amax, fused
+// column sums).  Other outputs are bf16: attention, LayerNorm and the heads are the bf16 path.
 #include "common.h"
 
 namespace {

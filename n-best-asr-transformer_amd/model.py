@@ -88,9 +88,10 @@ class NBestSTCModel(nn.Module):
         # "fp8w" (BASELINE configs[4]): forward GEMMs on the block-scaled fp8 MFMA from an e4m3 copy of the weights; the
         # master weights, the backward and everything between the GEMMs stay as in the bf16 path
         self.fp8_forward = bool(fp8_forward)
-        # ... and the four dgrad GEMMs of every layer from e4m3 copies of their gradient operands, scaled per tensor from the
-        # amax the same tensor had in the previous backward pass (delayed scaling); the first backward pass runs the bf16
-        # dgrads and only records the amax history.  Weight gradients stay bf16 x bf16 -> fp32.
+        # ... and the four dgrad and four weight-gradient GEMMs of every layer from e4m3 copies of their gradient operands, scaled
+        # per tensor from the amax the same tensor had in the previous backward pass (delayed scaling), times the e4m3 weight copy
+        # (dgrad) / the e4m3 activation copies the forward stashed per layer (wgrad, fp32 out); the first backward pass runs the
+        # bf16 GEMMs and only records the amax history.
         self.fp8_backward = self.fp8_forward if fp8_backward is None else bool(fp8_backward)
         self._gamax_gen = 0                # which of arena.gamax[0/1] holds the previous pass's amax
         self._gamax_valid = False
