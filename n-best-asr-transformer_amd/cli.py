@@ -88,9 +88,10 @@ def parse_arguments(argv=None):
     g.add_argument("--add_segment_ids", action="store_true")
     g = ap.add_argument_group("additive flags of this build")
     g.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8w"],
-                   help="bf16 (default) | f32 (parity path) | fp8w: the bf16 path with the forward GEMMs on the CDNA4 block-scaled fp8 "
-                        "MFMA from a per-matrix-scaled e4m3 copy of the weights (BASELINE configs[4]: 'fp8 weights'); master weights, "
-                        "backward and optimizer are unchanged")
+                   help="bf16 (default) | f32 (parity path) | fp8w: the bf16 path with every GEMM of the encoder layers (forward, input "
+                        "gradient, weight gradient) on the CDNA4 block-scaled fp8 MFMA, from per-matrix-scaled e4m3 copies of the weights "
+                        "and e4m3 copies of activations / gradients (BASELINE configs[4]: 'fp8 weights'); fp32 master weights, attention, "
+                        "LayerNorm, heads and the optimizer are unchanged")
     g.add_argument("--n_best", type=int, default=None, help="keep only the first n hypotheses of every utterance")
     g.add_argument("--init_checkpoint", default=None, help="state dict (reference keys) to start from")
     g.add_argument("--pretrained_path", default=None,
