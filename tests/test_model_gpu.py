@@ -316,7 +316,8 @@ def _check_vs_oracle(cfg, B, S, St, dtype, labels, fp8=False, fp8_bwd=False):
 
 
 @pytest.mark.parametrize("bwd8", [False, True])
-@pytest.mark.parametrize("family,B,S,St", [("bert", 3, 40, 12), ("bert", 2, 200, 40), ("xlmr-large", 2, 72, 24), ("bert", 2, 300, 40)])
+@pytest.mark.parametrize("family,B,S,St", [("bert", 3, 40, 12), ("bert", 2, 200, 40), ("xlmr-large", 2, 72, 24), ("bert", 2, 300, 40),
+                                           ("bert", 1, 9, 4)])      # last: 9 token rows - one ragged tile, weight gradients over K = 9 (< one k-stage)
 def test_fp8_forward_matches_its_oracle_leg(family, B, S, St, bwd8, labels):
     """"fp8w" (BASELINE configs[4]: fp8 weights on the CDNA4 fp8 MFMA): forward GEMMs - and with ``bwd8`` the dgrad AND weight-gradient
     GEMMs - on v_mfma_scale_f32_32x32x64_f8f6f4 from a per-matrix-scaled e4m3 copy of the weights; activations are cast to e4m3 (unit
