@@ -129,14 +129,21 @@ inline int nb_group_cols(int64_t tiles_n, int64_t slice_bytes_per_tile, int64_t 
 }
 
 // Streaming (nontemporal) store: for GEMM / attention outputs of tens to hundreds of MB, which otherwise wash the operands
-// other tiles still read out of the 4 MiB L2 of every XCD.
-// (inline asm: written as `nt ? __builtin_nontemporal_store : plain store` the optimiser merges the two stores of the diamond
-// into one plain store and the hint is gone)
+// other tiles still read out of the 4 MiB L2 of every XCD.  The shipped library streams EVERY GEMM output (nb_stream_output), so
+// the hint is unconditional there: `__builtin_nontemporal_store` (global_store ... nt), which the compiler schedules and whose
+// data registers it tracks.  (Round 2 selected it at run time through an inline-asm store inside an if / else: every store became
+// its own basic block with an `s_waitcnt vmcnt(0)` at the join - harmless behind an LDS restage that serialised the epilogue
+// anyway, 50 us per launch once the epilogue became one block of independent work.)  Experiment builds keep the run-time switch.
 template <typename V> __device__ __forceinline__ void st_stream(V* p, V v, bool nt) {
   static_assert(sizeof(V) == 8 || sizeof(V) == 16, "st_stream: 8- or 16-byte vectors");
+#ifdef NBEST_EXPERIMENTS
   if (!nt) { *p = v; return; }
-  if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#else
+  (void)nt;
+  __builtin_nontemporal_store(v, p);
+#endif
 }
 __device__ __forceinline__ void st_stream_bf16x8(bf16* p, const float* v, bool nt) {
   bf16x8 o;
@@ -144,6 +151,21 @@ __device__ __forceinline__ void st_stream_bf16x8(bf16* p, const float* v, bool n
   for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
   st_stream((bf16x8*)p, o, nt);
 }
+// Range-checked, nontemporal buffer stores / loads for the register epilogues of the bf16 GEMMs: the descriptor covers the M valid
+// rows, the hardware drops stores (returns zero for loads) past its end - ragged row tiles cost no branch, and without branches
+// the whole epilogue is one basic block whose loads, arithmetic and stores the compiler interleaves freely.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nb_bstore_bf16x8(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, byte_off, 0, 2 /* nt */);
+}
+__device__ __forceinline__ void nb_bstore8(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, uint32_t lo, uint32_t hi) {
+  __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo, hi}, rs, byte_off, 0, 2 /* nt */);
+}
+
 // host side: which GEMM outputs are streamed (bytes of the bf16 output)
 inline bool nb_stream_output(int64_t out_bytes) {
   int64_t min_mb = 0;

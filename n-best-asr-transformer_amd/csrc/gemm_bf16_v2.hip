@@ -43,6 +43,7 @@ struct GemmP2 {
   int64_t k_per_split;
   int tiles_m, tiles_n, splits, accumulate;
   uint32_t a_bytes, b_bytes;
+  uint32_t c_bytes, r_bytes, u_bytes;   // extents of the M valid rows of C / R / U (range-checked buffer access of the register epilogue)
   DropCfg drop;
   int stream_out;     // epilogue stores are nontemporal (common.h st_stream)
   int gn;             // tile columns per L2 group (common.h nb_tile_coords)
@@ -54,7 +55,9 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 }
 
 // one operand tile: ROWS x 32 bf16 = ROWS*4 16-byte chunks, 256 threads -> ROWS/64 DMA instructions per thread
-template <bool TR, int ROWS, int NT, int AUX = 0>
+// PW > 0 (k-contiguous B operand of the register-epilogue kernels): within every block of PW rows, LDS row 16 j + c is fetched
+// from operand row (PW / 16) * c + j
+template <bool TR, int ROWS, int NT, int AUX = 0, int PW = 0>
 __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid) {
   const int wave = tid >> 6;
 #pragma unroll
@@ -64,7 +67,9 @@ __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* til
     if (!TR) {
       const int row = p >> 2, slot = p & 3;
       const int kc = slot ^ ((-(row >> 2)) & 3);
-      voff = (uint32_t)(((row0 + row) * ld + k0 + kc * 8) * 2);
+      int grow = row;
+      if constexpr (PW > 0) { const int x = row % PW; grow = row - x + (PW / 16) * (x & 15) + (x >> 4); }
+      voff = (uint32_t)(((row0 + grow) * ld + k0 + kc * 8) * 2);
     } else {
       constexpr int CPR = ROWS / 8;  // 16-byte chunks per k-row
       const int krow = p / CPR, slot = p % CPR;
@@ -110,6 +115,15 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* tile, int row_base, int
   }
 }
 
+// Register epilogue of the k-contiguous ("NT") kernels with a bf16 output (kDirect).  The MFMA is issued UN-swapped there
+// (D = A . B: a lane holds 4 consecutive M rows 4g + e of ONE output column c = lane & 15 per 16x16 tile), and the B tile is
+// staged with its rows PERMUTED: LDS row 16 j + c of a wave's WTN-row block holds the weight row TNt * c + j (the LDS-DMA source
+// address is per lane, so the permutation is free and the LDS image, its swizzle and the fragment reads are untouched).  Tile j
+// of lane c is then output column TNt * c + j: for a fixed (i, e) a lane owns TNt CONSECUTIVE columns of row 16 i + 4 g + e, and
+// one wave-instruction stores 4 rows x (16 lanes x TNt x 2 B) - with 128-column wave tiles (TNt = 8) 16 bytes per lane, 256
+// contiguous bytes per row, whole 128-byte lines.  No LDS restage, no barrier, no branch (ragged row tiles: buffer range check).
+// (First attempt, kept the MFMA swapped with lane = row: every lane of a store wrote a different row - 64 partial 16-byte
+// requests per instruction - and the GEMMs got 5-10 % slower than with the LDS restage.)
 template <int N> __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -127,7 +141,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   constexpr bool PIPE = (BM == 128 && NT == 256);   // second fragment register set: fits only the 64x64 wave tile
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TMt = WTM / 16, TNt = WTN / 16;
-  static_assert(WTN == 64, "row-contiguous epilogue assumes 64-column wave tiles");
+  // k-contiguous operands with a bf16 output: un-swapped MFMA, permuted B rows, epilogue straight from the accumulators (see above)
+  constexpr bool kDirect = (!TA && !TB && EPI != NBEST_EPI_F32_SPLITK);
+  constexpr int kPW = kDirect ? WTN : 0;
+  static_assert(kDirect ? (WTN == 64 || WTN == 128) : WTN == 64, "LDS-restaged epilogue assumes 64-column wave tiles");
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int NDMA = (BM + BN) * 4 / NT;           // LDS-DMA instructions per thread and stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,11 +181,51 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }
   };
   f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
-  if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
+  if (kHasBias && !kDirect) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
   i32x4 pre[TMt / 2][4];   // chunk 0 is fetched before the K loop, the others right after it (fragment registers are dead then)
-  if (kPre) {
+  if (kPre && !kDirect) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) pre[0][it] = load_pre(erow0 + it * 8);
+  }
+  // register epilogue (kDirect): lane (dg, dc) owns, for every (i, e), the TNt consecutive columns dcol .. dcol + TNt - 1 of row
+  // drow0 + 16 i + e.  Output, residual and GELU' rows go through range-checked buffer descriptors (rows >= M: stores dropped,
+  // loads return zero): no branch anywhere.
+  const int dg = lane >> 4, dc = lane & 15;
+  const int64_t dcol = n0 + wn * WTN + TNt * dc;
+  const int64_t drow0 = m0 + wm * WTM + 4 * dg;
+  constexpr int NPRE0 = 1;   // 16-row tiles whose residual / GELU' rows are fetched before the K loop (the rest right after it)
+  float db[TNt];
+  u32x4 dpre[TMt][4];        // TNt = 8: 16 bytes of residual (8 bf16) per (i, e); TNt = 4: 8 bytes; GELU': TNt bytes
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.R, 0, p.r_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
+  const uint32_t voR = (uint32_t)((drow0 * p.ldr + dcol) * 2), voU = (uint32_t)(drow0 * p.ldu + dcol);
+  const uint32_t svR = (uint32_t)(2 * p.ldr), svU = (uint32_t)p.ldu;   // bytes per row
+  auto load_dpre = [&](int i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t rr = (uint32_t)(16 * i + e);
+      if constexpr (kHasR) {
+        if constexpr (TNt == 8) dpre[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rsR, voR + rr * svR, 0, 0);
+        else { const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rsR, voR + rr * svR, 0, 0); dpre[i][e] = u32x4{q[0], q[1], 0, 0}; }
+      } else if constexpr (kHasUin) {
+        if constexpr (TNt == 8) { const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rsU, voU + rr * svU, 0, 0); dpre[i][e] = u32x4{q[0], q[1], 0, 0}; }
+        else dpre[i][e] = u32x4{__builtin_amdgcn_raw_buffer_load_b32(rsU, voU + rr * svU, 0, 0), 0, 0, 0};
+      }
+    }
+  };
+  if constexpr (kDirect) {
+    if (kHasBias) {
+#pragma unroll
+      for (int q = 0; q < TNt / 4; ++q) {
+        const f32x4 b4 = *(const f32x4*)(p.bias + dcol + 4 * q);
+        db[4 * q] = b4[0]; db[4 * q + 1] = b4[1]; db[4 * q + 2] = b4[2]; db[4 * q + 3] = b4[3];
+      }
+    }
+    if (kHasR || kHasUin) {
+#pragma unroll
+      for (int i = 0; i < NPRE0; ++i) load_dpre(i);
+    }
   }
 
   f32x4 acc[TMt][TNt];
@@ -182,12 +239,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     // reads of stage j, LDS-DMA of stage j+STAGES-1, counted vmcnt) with an MFMA slot (stage j); group 1
     // runs one slot behind group 0, so on every SIMD one wave is always in its MFMA slot while the other
     // feeds itself.  One workgroup-wide s_barrier per slot keeps the two groups out of phase.
-    const int grp = __builtin_amdgcn_readfirstlane(wm);   // provably wave-uniform: the guarded s_barrier must be a scalar branch
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);   // waves 0-3 / 4-7 = one wave per SIMD each; provably wave-uniform: the guarded s_barrier must be a scalar branch
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
         stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0, kbeg + (int64_t)s0 * BK, p.lda, tid);
-        stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, p.ldb, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, p.ldb, tid);
       }
     }
     {
@@ -209,7 +266,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
         stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-        stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
       }
       const char* cur = lds + buf * STAGE;
       if ((DIAG & 2) == 0 || kt == 0) {
@@ -245,7 +302,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
         for (int i = 0; i < TMt; ++i)
 #pragma unroll
-          for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TNt; ++j) acc[i][j] = kDirect ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       } else {
 #pragma unroll
         for (int i = 0; i < TMt; ++i) asm volatile("" :: "v"(af[i]));
@@ -269,7 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   for (int s = 0; s < STAGES; ++s) {
     if (s < nk) {
       stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
-      stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
     }
   }
   bf16x8 afA[TMt], bfA[TNt], afB[TMt], bfB[TNt];
@@ -302,7 +360,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     if (kt + STAGES < nk) {                                                                                  \
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES) * BK;                                                 \
       stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + buf * STAGE, m0, k0, p.lda, tid);                                       \
-      stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, p.ldb, tid);                             \
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, p.ldb, tid);                             \
     }                                                                                                        \
     const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;                                                      \
     if (kt + 1 < nk) {                                                                                       \
@@ -312,7 +370,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }                                                                                                        \
     _Pragma("unroll") for (int i = 0; i < TMt; ++i)                                                          \
       _Pragma("unroll") for (int j = 0; j < TNt; ++j)                                                        \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[j], ac[i], acc[i][j], 0, 0, 0);               \
+        acc[i][j] = kDirect ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[i], bc[j], acc[i][j], 0, 0, 0)   \
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[j], ac[i], acc[i][j], 0, 0, 0);  \
     buf = nbuf;                                                                                              \
     ++kt;                                                                                                    \
   }
@@ -329,7 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   for (int s = 0; s < STAGES - 1; ++s) {
     if (s < nk) {
       stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
-      stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
     }
   }
   int buf = 0;
@@ -346,7 +405,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       if (nb >= STAGES) nb -= STAGES;
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
       stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-      stage_tile2<TB, BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
     }
     const char* cur = lds + buf * STAGE;
     bf16x8 af[TMt], bfr[TNt];
@@ -357,11 +416,96 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
     for (int i = 0; i < TMt; ++i)
 #pragma unroll
-      for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TNt; ++j) acc[i][j] = kDirect ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     buf = (buf + 1 == STAGES) ? 0 : buf + 1;
   }
   }
 
+  if constexpr (kDirect) {
+    // ---- epilogue straight from the accumulators: no LDS, no barrier, no branch; 4 x TMt independent groups of TNt elements per
+    // lane in one basic block, which the compiler is free to interleave (the GELU forms are ~25-instruction chains)
+    if (kHasR || kHasUin) {
+#pragma unroll
+      for (int i = NPRE0; i < TMt; ++i) load_dpre(i);
+    }
+    float colacc[TNt];
+#pragma unroll
+    for (int j = 0; j < TNt; ++j) colacc[j] = 0.f;
+    const uint32_t voC = (uint32_t)((drow0 * p.ldc + dcol) * 2), svC = (uint32_t)(2 * p.ldc);
+    const uint32_t dbase0 = (uint32_t)(drow0 * p.N + dcol), sD = (uint32_t)p.N;
+    const bool want_cols = p.colpart != nullptr;
+#pragma unroll
+    for (int i = 0; i < TMt; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t rr = (uint32_t)(16 * i + e);
+        float v[TNt];
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) v[j] = acc[i][j][e];
+        if (kHasBias) {
+#pragma unroll
+          for (int j = 0; j < TNt; ++j) v[j] += db[j];
+        }
+        if (EPI == NBEST_EPI_BIAS_GELU) {
+          float gp[TNt];
+#pragma unroll
+          for (int j = 0; j < TNt; j += 2) {
+            f32x2 h2, g2;   // gelu(u), and gelu'(u) kept for the backward
+            gelu_pair_fast(f32x2{v[j], v[j + 1]}, h2, g2);
+            gp[j] = g2[0]; gp[j + 1] = g2[1]; v[j] = h2[0]; v[j + 1] = h2[1];
+          }
+          if constexpr (TNt == 8) nb_bstore8(rsU, voU + rr * svU, gd_pack4(gp), gd_pack4(gp + 4));
+          else __builtin_amdgcn_raw_buffer_store_b32(gd_pack4(gp), rsU, voU + rr * svU, 0, 2);
+        }
+        if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
+          const uint32_t dbase = dbase0 + rr * sD;
+          uint32_t k = nb_keep4(p.drop, dbase);
+          if constexpr (TNt == 8) k |= nb_keep4(p.drop, dbase + 4) << 4;
+#pragma unroll
+          for (int j = 0; j < TNt; ++j) v[j] = (k >> j & 1) ? v[j] * p.drop.scale : 0.f;
+        }
+        if (kHasR) {
+          const bf16x8 r8 = __builtin_bit_cast(bf16x8, dpre[i][e]);
+#pragma unroll
+          for (int j = 0; j < TNt; ++j) v[j] += (float)r8[j];
+        }
+        if (kHasUin) {
+          float gd[8];
+          gd_unpack4(dpre[i][e][0], gd);
+          if constexpr (TNt == 8) gd_unpack4(dpre[i][e][1], gd + 4);
+#pragma unroll
+          for (int j = 0; j < TNt; ++j) v[j] *= gd[j];
+        }
+        if constexpr (TNt == 8) nb_bstore_bf16x8(rsC, voC + rr * svC, v);
+        else {
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsC, voC + rr * svC, 0, 2);
+        }
+        if (want_cols) {
+          const bool live = (drow0 + rr) < p.M;
+#pragma unroll
+          for (int j = 0; j < TNt; ++j) colacc[j] += live ? v[j] : 0.f;
+        }
+      }
+    }
+    if (want_cols) {   // fused bias gradient: sum over the 4 lane groups (rows 4g + e) -> one partial row per wave
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) {
+        float x = colacc[j];
+        x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+        colacc[j] = x;
+      }
+      if (dg == 0) {
+        float* o = p.colpart + ((int64_t)tile_m * WM + wm) * p.N + dcol;
+#pragma unroll
+        for (int q = 0; q < TNt / 4; ++q) *(f32x4*)(o + 4 * q) = f32x4{colacc[4 * q], colacc[4 * q + 1], colacc[4 * q + 2], colacc[4 * q + 3]};
+      }
+    }
+    return;
+  }
   // ---- epilogue: 32-row chunks restaged through wave-private LDS ([32][64] fp32, chunk16 ^= row & 15) ----
   float* ep = (float*)lds + wave * 2048;
   float colacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -500,6 +644,8 @@ __global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
   constexpr int WTM = 128, WTN = 64, TMt = 8, TNt = 4;
   constexpr int A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES;
   constexpr int NDMA = (BM + BN) * 4 / NT;   // 4
+  constexpr bool kDirect = false;            // LDS-restaged epilogue, swapped MFMA operands
+  constexpr int kPW = 0;
   constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU);
   constexpr int NSTORE = (WTM / 8) * (EPI == NBEST_EPI_BIAS_GELU ? 2 : 1);   // store instructions per wave and (full) tile
   constexpr int NBIAS = kHasBias ? 2 : 0;
@@ -588,7 +734,8 @@ __global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
 #pragma unroll
       for (int i = 0; i < TMt; ++i)
 #pragma unroll
-        for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TNt; ++j) acc[i][j] = kDirect ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -748,9 +895,16 @@ static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
     gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E><<<grid, NT, lds_bytes, st>>>(p);                                 \
     break;
+  if constexpr (BN / WN == 64) {   // the fp32 split-K output goes through the LDS-restaged epilogue (64-column wave tiles)
+    if (epi == NBEST_EPI_F32_SPLITK) {
+      switch (epi) { L(NBEST_EPI_F32_SPLITK) }
+      NB_LAUNCH_CHECK();
+      return NBEST_OK;
+    }
+  }
   switch (epi) {
     L(NBEST_EPI_NONE) L(NBEST_EPI_BIAS) L(NBEST_EPI_BIAS_GELU) L(NBEST_EPI_BIAS_DROP_RES) L(NBEST_EPI_DGELU)
-    L(NBEST_EPI_RES) L(NBEST_EPI_F32_SPLITK)
+    L(NBEST_EPI_RES)
     default:
       nbest_set_error("gemm: bad epilogue %d", epi);
       return NBEST_ERR_ARG;
@@ -772,7 +926,7 @@ size_t nbest_gemm_bf16_v2_ws_bytes(const nbest_gemm_args* a) {
   if (a->epilogue != NBEST_EPI_F32_SPLITK) {
     if (!a->colsum_out) return 0;
     const Plan pl0 = make_plan(a);
-    return (size_t)((a->M + pl0.bm - 1) / pl0.bm) * 2 * a->N * sizeof(float);
+    return (size_t)((a->M + pl0.bm - 1) / pl0.bm) * 4 * a->N * sizeof(float);   // one partial row per wave row of a tile (<= 4)
   }
   const Plan pl = make_plan(a);
   return pl.splits > 1 ? (size_t)pl.splits * a->M * a->N * sizeof(float) : 0;
@@ -806,6 +960,15 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
   const int64_t ab = ((a_rows - 1) * a->lda + a_cols) * 2, bb = ((b_rows - 1) * a->ldb + b_cols) * 2;
   NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm(bf16): operand larger than 4 GiB");
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  p.c_bytes = p.r_bytes = p.u_bytes = 0;
+  if (a->epilogue != NBEST_EPI_F32_SPLITK) {   // 32-bit byte offsets, also for the rows of a ragged last tile (dropped by the range check)
+    const int64_t mpad = a->M + 256;
+    NB_CHECK(mpad * a->ldc * 2 < ((int64_t)1 << 32) && mpad * a->ldr * 2 < ((int64_t)1 << 32) && mpad * a->ldu < ((int64_t)1 << 32),
+             NBEST_ERR_SHAPE, "gemm(bf16): output / residual larger than 4 GiB");
+    p.c_bytes = (uint32_t)(a->M * a->ldc * 2);
+    p.r_bytes = a->R ? (uint32_t)(a->M * a->ldr * 2) : 0;
+    p.u_bytes = a->U ? (uint32_t)(a->M * a->ldu) : 0;
+  }
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
   p.stream_out = nb_stream_output(a->M * a->N * 2) ? 1 : 0;
   // B is a weight matrix (k-contiguous [N][K]) in the forward / dgrad GEMMs; the weight gradients have no small operand
@@ -822,7 +985,7 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
     NB_CHECK(a->ws && a->ws_bytes >= (size_t)p.splits * a->M * a->N * sizeof(float), NBEST_ERR_WORKSPACE,
              "gemm: split-K workspace too small (%zu < %zu)", a->ws_bytes, (size_t)p.splits * a->M * a->N * sizeof(float));
   const int grid = p.tiles_m * p.tiles_n * p.splits;
-  int rc;
+  int rc, wave_rows = 2;   // wave rows per tile = partial rows of the fused column sums
   if (pl.bm == 128 && pl.bn == 256) {
     if (!a->trans_a && !a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, true>(p, epi, grid, st);
@@ -844,11 +1007,14 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
     rc = NBEST_OK;
 #endif
   } else if (pl.bm == 256 && pl.bn == 256) {
-    if (!a->trans_a && !a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, false>(p, epi, grid, st);
+    // k-contiguous operands: 4 x 2 waves with 64 x 128 wave tiles (register epilogue: 16-byte stores, whole 128-byte lines)
+    if (!a->trans_a && !a->trans_b && epi != NBEST_EPI_F32_SPLITK) { rc = launch2<256, 256, 4, 2, 4, false, false>(p, epi, grid, st); wave_rows = 4; }
+    else if (!a->trans_a && !a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, true>(p, epi, grid, st);
     else rc = launch2<256, 256, 2, 4, 4, true, true>(p, epi, grid, st);
   } else if (pl.bm == 256) {
-    if (!a->trans_b) rc = launch2<256, 128, 2, 2, 3, false, false>(p, epi, grid, st);
+    if (!a->trans_b && epi != NBEST_EPI_F32_SPLITK) { rc = launch2<256, 128, 4, 1, 3, false, false>(p, epi, grid, st); wave_rows = 4; }
+    else if (!a->trans_b) rc = launch2<256, 128, 2, 2, 3, false, false>(p, epi, grid, st);
     else rc = launch2<256, 128, 2, 2, 3, false, true>(p, epi, grid, st);
   } else {
     if (!a->trans_a && !a->trans_b) rc = launch2<128, 128, 2, 2, 4, false, false>(p, epi, grid, st);
@@ -856,7 +1022,7 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
     else rc = launch2<128, 128, 2, 2, 4, true, true>(p, epi, grid, st);
   }
   if (rc) return rc;
-  if (p.colpart) return nbest_internal_partial_rows_sum(p.colpart, p.tiles_m * 2, (int)a->N, a->colsum_out, a->colsum_accumulate, st);
+  if (p.colpart) return nbest_internal_partial_rows_sum(p.colpart, p.tiles_m * wave_rows, (int)a->N, a->colsum_out, a->colsum_accumulate, st);
   if (epi == NBEST_EPI_F32_SPLITK && p.splits > 1 && !(a->flags & NBEST_GEMM_DEFER_REDUCE)) {
     const int64_t MN = a->M * a->N;
     int64_t g = (MN / 4 + 255) / 256;

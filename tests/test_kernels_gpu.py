@@ -108,6 +108,57 @@ def test_gemm_bf16_bert_shapes():
               dY.float().t() @ A.float(), 1e-2)
 
 
+def _keep_mask(M, N, p, seed, stream):
+    """Independent restatement of the counter-based dropout decision (csrc/common.h nb_mix_key / nb_hash32 / nb_keep):
+    element idx = m * N + n is kept iff the 16-bit half of hash32((idx >> 1) * 0x9E3779B9 + key) selected by idx & 1 is >= thr16."""
+    m64 = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (stream + 1)) & m64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m64
+    key = (z ^ (z >> 31)) & 0xFFFFFFFF
+    thr = min(int(round(p * 65536)), 65535)
+    idx = torch.arange(M * N, device=DEV, dtype=torch.int64)
+    x = ((idx >> 1) * 0x9E3779B9 + key) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    u = torch.where((idx & 1) == 1, x >> 16, x & 0xFFFF)
+    return (u >= thr).view(M, N), 65536.0 / (65536 - thr)
+
+
+@pytest.mark.parametrize("N,K", [(2304, 768), (3072, 768), (768, 3072), (768, 768)])
+def test_gemm_bf16_register_epilogues_full_size(N, K):
+    """The layer GEMMs at the token count of BASELINE configs[1] minus a ragged tail (the 256-row tile kernels with the
+    register epilogue only run from ~1 000 tiles up): every epilogue against fp32 torch on the same bf16 inputs."""
+    M = 32768 - 88
+    A = rnd(M, K, dtype=torch.bfloat16, s=0.5, seed=31)
+    W = rnd(N, K, dtype=torch.bfloat16, s=0.05, seed=32)
+    bias = rnd(N, seed=33)
+    R = rnd(M, N, dtype=torch.bfloat16, seed=34)
+    ref = A.float() @ W.float().t()
+    tag = "gemm full-size N=%d K=%d" % (N, K)
+    guard = torch.full((M + 512, N), 7.0, dtype=torch.bfloat16, device=DEV)     # rows past M must stay untouched
+    out = guard[:M]
+    hb.gemm(A, W, M, N, K, out=out)
+    close(tag + " none", out, ref, 1e-2)
+    assert torch.all(guard[M:] == 7.0), "rows past M were written"
+    close(tag + " bias", hb.gemm(A, W, M, N, K, epilogue=hb.EPI_BIAS, bias=bias), ref + bias, 1e-2)
+    o, U = hb.gemm(A, W, M, N, K, epilogue=hb.EPI_BIAS_GELU, bias=bias)
+    close(tag + " bias_gelu.C", o, gelu(ref + bias), 1e-2)
+    gerr = (hb.gelu_d_decode(U) - dgelu(ref + bias)).abs().max().item()
+    _log("%-58s abs_err=%.3e" % (tag + " bias_gelu.U 8-bit", gerr))
+    assert gerr <= 2.6e-3 + 4e-3, gerr
+    close(tag + " res", hb.gemm(A, W, M, N, K, epilogue=hb.EPI_RES, R=R), ref + R.float(), 1e-2)
+    y = hb.gemm(A, W, M, N, K, epilogue=hb.EPI_BIAS_DROP_RES, bias=bias, R=R, drop_p=0.1, seed=11, drop_stream=5).float()
+    keep, scale = _keep_mask(M, N, 0.1, 11, 5)
+    close(tag + " bias_drop_res", y, torch.where(keep, (ref + bias) * scale, torch.zeros_like(ref)) + R.float(), 1e-2)
+    Uin = hb.gelu_d_encode(dgelu(rnd(M, N, seed=35)))
+    Ud = hb.gelu_d_decode(Uin)
+    cs = torch.zeros(N, device=DEV)
+    close(tag + " dgelu", hb.gemm(A, W, M, N, K, epilogue=hb.EPI_DGELU, U=Uin, colsum_out=cs), ref * Ud, 1e-2)
+    close(tag + " dgelu fused column sums", cs, (ref * Ud).sum(0), 5e-2)
+
+
 def test_gemm_dropout_mask_is_shared_with_layernorm_bwd():
     M, N, K, p = 256, 256, 64, 0.25
     A = rnd(M, K, dtype=torch.bfloat16, seed=21)
