@@ -140,7 +140,7 @@ typedef struct nbest_gemm_fp8_args {
   const float* out_scale_dev; /* optional DEVICE scalar that overrides out_scale (scales produced on the device by
                                  nbest_quantize_weights_fp8: no host round trip) */
   /* ---- dgrad use (epilogues NONE, RES, DGELU): A8 is the e4m3 copy of a GRADIENT tensor, e4m3(g * s) with
-   * s = 2^floor(log2(224 / amax)) of the amax stored (as float bits) at a_amax; the accumulator is divided by s.
+   * s = 2^floor(log2(56 / amax)) of the amax stored (as float bits) at a_amax; the accumulator is divided by s.
    * DGELU: C = acc * gelu'(U) in bf16; optional C8 = e4m3(C * s_c), s_c from *c8_amax_prev; *c8_amax_new = max(|C|) (atomic);
    * optional colsum_out[N] (+)= column sums of C (the FFN-up bias gradient), needs ws >= nbest_gemm_fp8_ws_bytes().   */
   const uint32_t* a_amax;

@@ -217,36 +217,50 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
   store_tile(img, row0, o0, o1, lane, gbase, gld, rows_valid, g8, s8, unused, false);
 }
 
+// NKB <= 4 (S <= 128): every wave owns exactly one 32-query block, so (a) its Q fragments are fetched BEFORE the wait for the
+// K / V tiles (one memory round trip less on the critical path of a 10-us workgroup) and (b) K is dead once the scores exist:
+// after a barrier the per-wave output images reuse its rows, the workgroup needs 2 x Sp x 128 B (32.5 KiB at S = 128) instead
+// of 48.5 KiB - four workgroups per CU instead of three, with the registers capped at 128 for that (launch bounds).  The kernel
+// is bound by memory latency (0.8 MB in flight per workgroup, ~10 us each), not by arithmetic: residency is what it wants.
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                             bf16* __restrict__ ctx, float* __restrict__ lse, int S, int heads,
                                                             int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int Sp = NKB * 32;
+  constexpr bool kOne = (NKB <= 4);           // one query block per wave
   char* Kt = lds;
   char* Vt = lds + Sp * 128;
   float* madd = (float*)(lds + 2 * Sp * 128);
-  char* Ost = lds + 2 * Sp * 128 + Sp * 4;  // 4 x 4 KiB, one [32][64] image per wave
+  char* Ost = kOne ? Kt : lds + 2 * Sp * 128 + Sp * 4;  // 4 x 4 KiB, one [32][64] image per wave (kOne: over K, see above)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
   const int ld = 3 * H;
   const bf16* base = qkv + (int64_t)b * S * ld;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(S * ld * 2), 0x00020000);
-  stage_rows(rs, Kt, Sp, H + h * 64, ld, tid);
-  stage_rows(rs, Vt, Sp, 2 * H + h * 64, ld, tid);
-  for (int k = tid; k < Sp; k += 256) madd[k] = (k < S && mask[b * S + k]) ? 0.f : -INFINITY;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int qb = wave; qb < NKB; qb += 4) {
-    const int q0 = 32 * qb, qrow = q0 + (lane & 31);
-    bf16x8 qf[4];
+  auto load_q = [&](int qb, bf16x8* qf) {
+    const int qrow = 32 * qb + (lane & 31);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const i32x4 raw = (qrow < S) ? *(const i32x4*)(base + (int64_t)qrow * ld + h * 64 + 16 * ks + 8 * hh) : i32x4{0, 0, 0, 0};
       qf[ks] = __builtin_bit_cast(bf16x8, raw);
     }
+  };
+  bf16x8 qf[4];
+  if (kOne) load_q(wave, qf);
+  stage_rows(rs, Kt, Sp, H + h * 64, ld, tid);
+  stage_rows(rs, Vt, Sp, 2 * H + h * 64, ld, tid);
+  for (int k = tid; k < Sp; k += 256) madd[k] = (k < S && mask[b * S + k]) ? 0.f : -INFINITY;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float sl2 = scale * 1.4426950408889634f;   // scores in units of log2: exp(x) = exp2(x log2 e), one multiply less per element
+
+  for (int qb = wave; qb < (kOne ? wave + 1 : NKB); qb += 4) {
+    const int q0 = 32 * qb, qrow = q0 + (lane & 31);
+    const bool active = qb < NKB;            // kOne: the waves beyond the last query block still take part in the barrier below
+    if (!kOne) load_q(qb, qf);
     f32x16 sc[NKB];
+    if (active) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       f32x16 a;
@@ -256,6 +270,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
       for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, 32 * kb, ks, lane), qf[ks], a, 0, 0, 0);
       sc[kb] = a;
     }
+    }
+    if (kOne) __syncthreads();               // every wave has read its K fragments: the K rows become the output images
+    if (!active) continue;
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
         const f32x4 ma = *(const f32x4*)(madd + 32 * kb + 8 * r4 + 4 * hh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = sc[kb][4 * r4 + e] * scale + ma[e];
+          const float v = sc[kb][4 * r4 + e] * sl2 + ma[e];
           sc[kb][4 * r4 + e] = v;
           mx = fmaxf(mx, v);
         }
@@ -276,25 +293,33 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __expf(sc[kb][r] - mxs);
+        const float pv = __builtin_amdgcn_exp2f(sc[kb][r] - mxs);
         sc[kb][r] = pv;
         sum += pv;
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (hh == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = mxs + __logf(sum);
+    if (hh == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = mxs * 0.6931471805599453f + __logf(sum);
+    // normalise (+ dropout) and round to bf16 at once: the probabilities are the A operand of the P.V MFMA (k order of an
+    // accumulator tile, see acc_to_frag) - kept as packed bf16 they occupy half the registers of the fp32 scores
+    bf16x8 pa[NKB][2];
     if (drop.thr16 && (S & 1) == 0) {
       // registers (2j, 2j+1) hold keys (k, k+1) with k even: with S even they are one element pair of the counter
       // stream, so one hash decides both
+      // counter of the pair = (row base + key) / 2 with an even row base: its product with the hash's odd constant splits into a
+      // per-lane term and a compile-time term per register - no 32-bit multiply (quarter rate) per pair for the index
       const uint32_t rowbase = (uint32_t)((bh * S + qrow) * S);
+      const uint32_t hb = ((rowbase >> 1) + 2u * (uint32_t)hh) * 0x9E3779B9U + drop.key;
+      const float ids = inv * drop.scale;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const uint32_t idx = rowbase + (uint32_t)(32 * kb + crow(r, hh));
-          const uint32_t hsh = nb_hash32((idx >> 1) * 0x9E3779B9U + drop.key);
-          sc[kb][r] = ((hsh & 0xFFFFu) >= drop.thr16) ? sc[kb][r] * (inv * drop.scale) : 0.f;
-          sc[kb][r + 1] = ((hsh >> 16) >= drop.thr16) ? sc[kb][r + 1] * (inv * drop.scale) : 0.f;
+          const uint32_t hsh = nb_hash32(hb + (uint32_t)((32 * kb + crow(r, 0)) >> 1) * 0x9E3779B9U);
+          const float p0 = ((hsh & 0xFFFFu) >= drop.thr16) ? sc[kb][r] * ids : 0.f;
+          const float p1 = ((hsh >> 16) >= drop.thr16) ? sc[kb][r + 1] * ids : 0.f;
+          pa[kb][r >> 3][r & 7] = (bf16)p0;
+          pa[kb][r >> 3][(r & 7) + 1] = (bf16)p1;
         }
     } else {
 #pragma unroll
@@ -306,7 +331,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
             const int key = 32 * kb + crow(r, hh);
             pv = nb_keep(drop, (uint32_t)((bh * S + qrow) * S + key)) ? pv * drop.scale : 0.f;
           }
-          sc[kb][r] = pv;
+          pa[kb][r >> 3][r & 7] = (bf16)pv;
         }
     }
     f32x16 o0, o1;
@@ -316,9 +341,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 pa = acc_to_frag(sc[kb], s);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 0, lane), o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag<true>(Vt, 32 * kb + 16 * s, 32, lane), o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[kb][s], tr_frag<true>(Vt, 32 * kb + 16 * s, 0, lane), o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[kb][s], tr_frag<true>(Vt, 32 * kb + 16 * s, 32, lane), o1, 0, 0, 0);
       }
     store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0,
                ctx8 ? ctx8 + ((int64_t)b * S + q0) * H + h * 64 : nullptr);
@@ -986,7 +1010,11 @@ static void launch_bwd2(const bf16* qkv, const uint8_t* mask, const bf16* ctx, c
   attn_bwd2_bf16_kernel<NKB><<<B * heads, (NKB <= 4 ? 4 : 8) * 64, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d, f8);
 }
 
-static size_t fwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * 256 + (size_t)nkb * 32 * 4 + 4 * 4096; }
+// K | V | key-mask addends (| 4 output images; S <= 128 restages the output over the K rows, which are dead by then)
+static size_t fwd_lds_bytes(int nkb) {
+  const size_t kv = (size_t)nkb * 32 * 256, madd = (size_t)nkb * 32 * 4;
+  return (nkb <= 4) ? kv + madd : kv + madd + 4 * 4096;
+}
 #ifdef NBEST_EXPERIMENTS
 static size_t bwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * (4 * 128 + 256) + (size_t)nkb * 32 * 12; }
 #endif

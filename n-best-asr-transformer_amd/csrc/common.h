@@ -156,6 +156,7 @@ __device__ __forceinline__ void st_stream_bf16x8(bf16* p, const float* v, bool n
 // the whole epilogue is one basic block whose loads, arithmetic and stores the compiler interleaves freely.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ void nb_bstore_bf16x8(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, const float* v) {
   bf16x8 o;
 #pragma unroll
@@ -323,15 +324,27 @@ __device__ __forceinline__ uint32_t fp8_pack4(const float* v) {
 }
 
 // fp8 copy of a GRADIENT tensor for the fp8 dgrad GEMMs: e4m3(g * s) with the per-tensor power-of-two scale
-// s = 2^floor(log2(224 / amax)) taken from the amax the SAME tensor had in the previous backward pass (delayed scaling);
+// s = 2^floor(log2(56 / amax)) taken from the amax the SAME tensor had in the previous backward pass (delayed scaling);
 // the producer also records this pass's amax (bits of a non-negative float order like the float).  All-null = off.
+// Headroom: the history is ONE step old, so the scale maps it to 56 = 448 / 8 - a gradient may grow 8 x from one step to the
+// next (first real batch after the calibration pass, a loss spike) before anything saturates; the price is 2 of the 17.8 bits
+// of e4m3 range at the bottom (elements below amax * 2^-14.8 flush), where a gradient tensor's mass is not (round 2 kept 2 x
+// headroom, 224, and saturated silently; tests/test_model_gpu.py::test_fp8w_gradient_amax_jump).
+// Weights (static, re-quantised from the master after every step) keep 2 x: fp8_scale_of.
 struct Fp8Grad {
   uint8_t* out8;
   const uint32_t* amax_prev;
   uint32_t* amax_new;
 };
-__host__ __device__ __forceinline__ float fp8_scale_of(float amax) { return amax > 0.f ? exp2f(floorf(log2f(224.f / amax))) : 1.f; }
-__device__ __forceinline__ float fp8_grad_scale(const uint32_t* amax_prev) { return amax_prev ? fp8_scale_of(__uint_as_float(*amax_prev)) : 1.f; }
+// 2^floor(log2(target / amax)), exponent clamped to +-100; a zero, denormal (< 2^-100) or non-finite amax gives scale 1
+__host__ __device__ __forceinline__ float fp8_pow2_scale(float amax, float target) {
+  if (!(amax >= 7.8886e-31f) || !(amax <= 3.0e38f)) return 1.f;      // also catches NaN
+  const float e = floorf(log2f(target / amax));
+  return exp2f(e < -100.f ? -100.f : (e > 100.f ? 100.f : e));
+}
+__host__ __device__ __forceinline__ float fp8_scale_of(float amax) { return fp8_pow2_scale(amax, 224.f); }        // weights
+__host__ __device__ __forceinline__ float fp8_gscale_of(float amax) { return fp8_pow2_scale(amax, 56.f); }        // gradients
+__device__ __forceinline__ float fp8_grad_scale(const uint32_t* amax_prev) { return amax_prev ? fp8_gscale_of(__uint_as_float(*amax_prev)) : 1.f; }
 // *p = max(*p, v) for one lane of a wave.  Thousands of waves update the same word: an unconditional atomicMax from each
 // serialises at the L2 (measured: +66 us on a 126 us kernel for 12 288 atomics); reading first lets all but the few waves
 // that actually raise the maximum skip the atomic.
@@ -364,6 +377,11 @@ __device__ __forceinline__ bool nb_keep(const DropCfg& d, uint32_t idx) {
   const uint32_t h = nb_hash32((idx >> 1) * 0x9E3779B9U + d.key);
   const uint32_t u = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
   return u >= d.thr16;
+}
+// decisions for the element pair idx, idx + 1 (idx even): bit i set = keep
+__device__ __forceinline__ uint32_t nb_keep2(const DropCfg& d, uint32_t idx) {
+  const uint32_t h = nb_hash32((idx >> 1) * 0x9E3779B9U + d.key);
+  return ((h & 0xFFFFu) >= d.thr16 ? 1u : 0u) | ((h >> 16) >= d.thr16 ? 2u : 0u);
 }
 // decisions for 4 consecutive elements idx..idx+3 (idx % 4 == 0): bit i set = keep
 __device__ __forceinline__ uint32_t nb_keep4(const DropCfg& d, uint32_t idx) {

@@ -56,12 +56,18 @@ __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
 
 // one operand tile: ROWS x 32 bf16 = ROWS*4 16-byte chunks, 256 threads -> ROWS/64 DMA instructions per thread
 // PW > 0 (k-contiguous B operand of the register-epilogue kernels): within every block of PW rows, LDS row 16 j + c is fetched
-// from operand row (PW / 16) * c + j
+// from operand row (PW / 16) * c + j.
+// ROWS * 4 chunks over NT threads need not divide (192-row B tile, 512 threads: 1.5 instructions per thread): the last instruction
+// is issued by EVERY wave so that all waves count the same number of LDS-DMA operations per stage (the counted s_waitcnt vmcnt of
+// the ring assume it); the waves with no chunk left read past the end of the buffer (range check: zero fill, no memory traffic)
+// into their own 1-KiB slot of `dump`.
 template <bool TR, int ROWS, int NT, int AUX = 0, int PW = 0>
-__device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid) {
+__device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t row0, int64_t k0, int64_t ld, int tid,
+                                            char* dump = nullptr) {
   const int wave = tid >> 6;
+  constexpr int NI = (ROWS * 4 + NT - 1) / NT;
 #pragma unroll
-  for (int i = 0; i < ROWS * 4 / NT; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int p = i * NT + tid;
     uint32_t voff;
     if (!TR) {
@@ -76,7 +82,14 @@ __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* til
       const int mc = slot ^ (2 * (krow & 3) + 8 * ((krow >> 3) & 1));
       voff = (uint32_t)(((k0 + krow) * ld + row0 + mc * 8) * 2);
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, voff, 0, 0, AUX);
+    char* dst = tile + (i * NT + wave * 64) * 16;
+    if constexpr ((ROWS * 4) % NT != 0) {
+      if (i == NI - 1 && (i * NT + wave * 64) * 16 >= ROWS * 64) {   // wave-uniform: this wave has no chunk in the last instruction
+        voff = 0xFFFFFFF0u;
+        dst = dump + (wave % (NT / 64)) * 1024;
+      }
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, 0, 0, AUX);
   }
 }
 
@@ -144,9 +157,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   // k-contiguous operands with a bf16 output: un-swapped MFMA, permuted B rows, epilogue straight from the accumulators (see above)
   constexpr bool kDirect = (!TA && !TB && EPI != NBEST_EPI_F32_SPLITK);
   constexpr int kPW = kDirect ? WTN : 0;
-  static_assert(kDirect ? (WTN == 64 || WTN == 128) : WTN == 64, "LDS-restaged epilogue assumes 64-column wave tiles");
+  static_assert(kDirect ? (WTN == 64 || WTN == 96 || WTN == 128) : WTN == 64, "LDS-restaged epilogue assumes 64-column wave tiles");
+  static_assert(TNt != 6 || (EPI != NBEST_EPI_BIAS_GELU && EPI != NBEST_EPI_DGELU), "96-column wave tiles: no GELU epilogues (8-bit rows)");
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int NDMA = (BM + BN) * 4 / NT;           // LDS-DMA instructions per thread and stage
+  constexpr int NDMA = (BM * 4 + NT - 1) / NT + (BN * 4 + NT - 1) / NT;   // LDS-DMA instructions per thread and stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   const int64_t drow0 = m0 + wm * WTM + 4 * dg;
   constexpr int NPRE0 = 1;   // 16-row tiles whose residual / GELU' rows are fetched before the K loop (the rest right after it)
   float db[TNt];
-  u32x4 dpre[TMt][4];        // TNt = 8: 16 bytes of residual (8 bf16) per (i, e); TNt = 4: 8 bytes; GELU': TNt bytes
+  u32x4 dpre[TMt][4];        // TNt = 8: 16 bytes of residual (8 bf16) per (i, e); TNt = 6: 12 bytes; TNt = 4: 8 bytes; GELU': TNt bytes
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.R, 0, p.r_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
@@ -207,6 +221,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       const uint32_t rr = (uint32_t)(16 * i + e);
       if constexpr (kHasR) {
         if constexpr (TNt == 8) dpre[i][e] = __builtin_amdgcn_raw_buffer_load_b128(rsR, voR + rr * svR, 0, 0);
+        else if constexpr (TNt == 6) { const u32x3 q = __builtin_amdgcn_raw_buffer_load_b96(rsR, voR + rr * svR, 0, 0); dpre[i][e] = u32x4{q[0], q[1], q[2], 0}; }
         else { const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rsR, voR + rr * svR, 0, 0); dpre[i][e] = u32x4{q[0], q[1], 0, 0}; }
       } else if constexpr (kHasUin) {
         if constexpr (TNt == 8) { const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rsU, voU + rr * svU, 0, 0); dpre[i][e] = u32x4{q[0], q[1], 0, 0}; }
@@ -217,9 +232,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   if constexpr (kDirect) {
     if (kHasBias) {
 #pragma unroll
-      for (int q = 0; q < TNt / 4; ++q) {
-        const f32x4 b4 = *(const f32x4*)(p.bias + dcol + 4 * q);
-        db[4 * q] = b4[0]; db[4 * q + 1] = b4[1]; db[4 * q + 2] = b4[2]; db[4 * q + 3] = b4[3];
+      for (int q = 0; q < TNt / 2; ++q) {
+        const f32x2 b2 = *(const f32x2*)(p.bias + dcol + 2 * q);
+        db[2 * q] = b2[0]; db[2 * q + 1] = b2[1];
       }
     }
     if (kHasR || kHasUin) {
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
         stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0, kbeg + (int64_t)s0 * BK, p.lda, tid);
-        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, p.ldb, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, p.ldb, tid, lds + STAGES * STAGE);
       }
     }
     {
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
         stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid, lds + STAGES * STAGE);
       }
       const char* cur = lds + buf * STAGE;
       if ((DIAG & 2) == 0 || kt == 0) {
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       if (nb >= STAGES) nb -= STAGES;
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
       stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid, lds + STAGES * STAGE);
     }
     const char* cur = lds + buf * STAGE;
     bf16x8 af[TMt], bfr[TNt];
@@ -460,8 +475,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         }
         if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
           const uint32_t dbase = dbase0 + rr * sD;
-          uint32_t k = nb_keep4(p.drop, dbase);
-          if constexpr (TNt == 8) k |= nb_keep4(p.drop, dbase + 4) << 4;
+          uint32_t k = 0;       // dbase is even: one hash per element pair
+#pragma unroll
+          for (int q = 0; q < TNt / 2; ++q) k |= nb_keep2(p.drop, dbase + 2 * q) << (2 * q);
 #pragma unroll
           for (int j = 0; j < TNt; ++j) v[j] = (k >> j & 1) ? v[j] * p.drop.scale : 0.f;
         }
@@ -478,7 +494,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
           for (int j = 0; j < TNt; ++j) v[j] *= gd[j];
         }
         if constexpr (TNt == 8) nb_bstore_bf16x8(rsC, voC + rr * svC, v);
-        else {
+        else if constexpr (TNt == 6) {
+          bf16x2 o0 = {(bf16)v[0], (bf16)v[1]}, o1 = {(bf16)v[2], (bf16)v[3]}, o2 = {(bf16)v[4], (bf16)v[5]};
+          __builtin_amdgcn_raw_buffer_store_b96(u32x3{__builtin_bit_cast(uint32_t, o0), __builtin_bit_cast(uint32_t, o1), __builtin_bit_cast(uint32_t, o2)},
+                                                rsC, voC + rr * svC, 0, 2);
+        } else {
           bf16x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
@@ -501,7 +521,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       if (dg == 0) {
         float* o = p.colpart + ((int64_t)tile_m * WM + wm) * p.N + dcol;
 #pragma unroll
-        for (int q = 0; q < TNt / 4; ++q) *(f32x4*)(o + 4 * q) = f32x4{colacc[4 * q], colacc[4 * q + 1], colacc[4 * q + 2], colacc[4 * q + 3]};
+        for (int q = 0; q < TNt / 2; ++q) *(f32x2*)(o + 2 * q) = f32x2{colacc[2 * q], colacc[2 * q + 1]};
       }
     }
     return;
@@ -835,6 +855,7 @@ static int forced_tile() {
     const char* e = getenv("NBEST_TILE");
     if (!e) return 0;
     if (!strcmp(e, "256x256")) return 3;
+    if (!strcmp(e, "256x192")) return 5;
     if (!strcmp(e, "128x256")) return 4;
     if (!strcmp(e, "256x128")) return 2;
     if (!strcmp(e, "128x128")) return 1;
@@ -866,8 +887,23 @@ static Plan make_plan(const nbest_gemm_args* a) {
     pl.bm = 256; pl.bn = 256;   // weight gradients with >= 18 output tiles (QKV, FFN): 1.0-1.05 PFLOP/s vs 0.85-0.94 for v1;
                                 // the 768x768 attention-output gradient (9 tiles, 28 splits) stays on v1 (0.90 vs 0.79)
   }
+  // 256 x 192 tiles (ping-pong, 4 x 2 waves of 64 x 96 columns): N = 768 gives 4 x (M / 256) tiles - 512 = exactly two rounds on the
+  // 256 CUs at M = 32 768, where 256 x 256 tiles give 384 = one and a half (a quarter of the chip idle for half the kernel) and
+  // the 128 x 128 kernel three rounds of a structure that tops out near 1 PFLOP/s.  Chosen when its rounds are fuller (a 6 %
+  // handicap for the smaller tile: 24 instead of 32 MFMAs per barrier pair); plain / bias / residual epilogues only.
+  {
+    const bool epi192 = a->epilogue == NBEST_EPI_NONE || a->epilogue == NBEST_EPI_BIAS || a->epilogue == NBEST_EPI_BIAS_DROP_RES ||
+                        a->epilogue == NBEST_EPI_RES;
+    if (!a->trans_a && !a->trans_b && a->N % 192 == 0 && epi192 && (ft == 0 || ft == 5)) {
+      const int64_t rows = (a->M + 255) / 256, t192 = rows * (a->N / 192);
+      auto eff = [](int64_t t) { return (double)t / (double)(((t + 255) / 256) * 256); };
+      const double e256 = (a->N % 256 == 0) ? eff(rows * (a->N / 256)) : 0.0;
+      const double ecur = (pl.bm == 256 && pl.bn == 256) ? e256 : (a->N % 256 == 0 ? e256 : 0.0);
+      if (ft == 5 || (t192 >= 512 && 0.94 * eff(t192) > ecur)) { pl.bm = 256; pl.bn = 192; }
+    }
+  }
   const int64_t tiles = ((a->M + pl.bm - 1) / pl.bm) * (a->N / pl.bn);
-  const int64_t slots = (pl.bn == 256) ? 256 : 512;   // workgroups resident at once
+  const int64_t slots = (pl.bn >= 192) ? 256 : 512;   // workgroups resident at once
   int64_t splits = 1;
   if (a->epilogue == NBEST_EPI_F32_SPLITK) {
     const int64_t maxs = (a->K / 512 < 1) ? 1 : ((a->K / 512 > 32) ? 32 : a->K / 512);
@@ -888,8 +924,8 @@ static Plan make_plan(const nbest_gemm_args* a) {
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB>
 static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
-  constexpr int lds_bytes = STAGES * (BM + BN) * BK * 2;
   constexpr int NT = WM * WN * 64;
+  constexpr int lds_bytes = STAGES * (BM + BN) * BK * 2 + (((BN * 4) % NT) ? (NT / 64) * 1024 : 0);   // + the zero-fill dump slots
 #define L(E)                                                                                                        \
   case E:                                                                                                           \
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
@@ -902,12 +938,21 @@ static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
       return NBEST_OK;
     }
   }
-  switch (epi) {
-    L(NBEST_EPI_NONE) L(NBEST_EPI_BIAS) L(NBEST_EPI_BIAS_GELU) L(NBEST_EPI_BIAS_DROP_RES) L(NBEST_EPI_DGELU)
-    L(NBEST_EPI_RES)
-    default:
-      nbest_set_error("gemm: bad epilogue %d", epi);
-      return NBEST_ERR_ARG;
+  if constexpr (BN / WN == 96) {   // 96-column wave tiles: no 8-bit GELU' rows
+    switch (epi) {
+      L(NBEST_EPI_NONE) L(NBEST_EPI_BIAS) L(NBEST_EPI_BIAS_DROP_RES) L(NBEST_EPI_RES)
+      default:
+        nbest_set_error("gemm: epilogue %d is not built for 192-column tiles", epi);
+        return NBEST_ERR_ARG;
+    }
+  } else {
+    switch (epi) {
+      L(NBEST_EPI_NONE) L(NBEST_EPI_BIAS) L(NBEST_EPI_BIAS_GELU) L(NBEST_EPI_BIAS_DROP_RES) L(NBEST_EPI_DGELU)
+      L(NBEST_EPI_RES)
+      default:
+        nbest_set_error("gemm: bad epilogue %d", epi);
+        return NBEST_ERR_ARG;
+    }
   }
 #undef L
   NB_LAUNCH_CHECK();
@@ -933,7 +978,7 @@ size_t nbest_gemm_bf16_v2_ws_bytes(const nbest_gemm_args* a) {
 }
 
 int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
-  NB_CHECK(a->N % 128 == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld must be a multiple of 128", (long long)a->N);
+  NB_CHECK(a->N % 64 == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld must be a multiple of 64", (long long)a->N);
   NB_CHECK(a->trans_a || a->K % BK == 0, NBEST_ERR_SHAPE, "gemm(bf16): K=%lld must be a multiple of %d", (long long)a->K, BK);
   NB_CHECK(!(a->trans_a && !a->trans_b), NBEST_ERR_ARG, "gemm(bf16): trans_a without trans_b is not built");
   NB_CHECK(!a->trans_a || a->M % 128 == 0, NBEST_ERR_SHAPE, "gemm(bf16): trans_a needs M %% 128 == 0");
@@ -986,7 +1031,10 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
              "gemm: split-K workspace too small (%zu < %zu)", a->ws_bytes, (size_t)p.splits * a->M * a->N * sizeof(float));
   const int grid = p.tiles_m * p.tiles_n * p.splits;
   int rc, wave_rows = 2;   // wave rows per tile = partial rows of the fused column sums
-  if (pl.bm == 128 && pl.bn == 256) {
+  NB_CHECK(a->N % pl.bn == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld is not a multiple of the %d-column tile", (long long)a->N, pl.bn);
+  if (pl.bm == 256 && pl.bn == 192) {
+    rc = launch2<256, 192, 4, 2, 4, false, false>(p, epi, grid, st); wave_rows = 4;
+  } else if (pl.bm == 128 && pl.bn == 256) {
     if (!a->trans_a && !a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, true>(p, epi, grid, st);
     else rc = launch2<128, 256, 2, 4, 4, true, true>(p, epi, grid, st);

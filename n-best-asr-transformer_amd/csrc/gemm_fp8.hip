@@ -41,7 +41,7 @@ struct GemmP8 {
   uint32_t a_bytes, b_bytes;
   float out_scale;
   const float* out_scale_dev;
-  const uint32_t* a_amax;      // dgrad: A8 = e4m3(gradient * s), s from this amax (fp8_scale_of): the accumulator is divided by s
+  const uint32_t* a_amax;      // dgrad: A8 = e4m3(gradient * s), s from this amax (fp8_gscale_of): the accumulator is divided by s
   Fp8Grad c8g;                 // DGELU: e4m3 copy of the output gradient (scaled by ITS previous amax) + its new amax
   float* colpart;              // DGELU: fused column sums of the output (bias gradient), partial rows [tiles_m * 2][N]
   DropCfg drop;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
   f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
   if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
   float oscale = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;
-  if (p.a_amax) oscale /= fp8_scale_of(__uint_as_float(*p.a_amax));
+  if (p.a_amax) oscale /= fp8_gscale_of(__uint_as_float(*p.a_amax));
   const float c8s = fp8_grad_scale(p.c8g.amax_prev);
   float amax8 = 0.f;
   auto load_pre = [&](int64_t m) -> i32x4 {   // residual rows: bf16, 16 bytes per lane; GELU' rows: 8-bit, 8 bytes per lane
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
   const int nk = (int)((kend - kbeg + BK8 - 1) / BK8);     // token rows past K are zero-filled by the buffer range check
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  const float oscale = p.a_amax ? 1.f / fp8_scale_of(__uint_as_float(*p.a_amax)) : 1.f;
+  const float oscale = p.a_amax ? 1.f / fp8_gscale_of(__uint_as_float(*p.a_amax)) : 1.f;
 
   f32x16 acc[TMb][TNb];
 #pragma unroll

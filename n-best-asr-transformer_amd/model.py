@@ -121,13 +121,23 @@ class NBestSTCModel(nn.Module):
     def zero_grad(self, set_to_none=False):
         self.arena.g.zero_()
 
+    def _drop_fp8_history(self):
+        """new weights: the gradient amax history of the fp8 backward belongs to the old ones - the next backward pass runs the
+        bf16 GEMMs and records a fresh one (as the very first pass does)"""
+        if self.fp8_backward and self._gamax_valid:
+            self._gamax_valid = False
+            for t in self.arena.gamax:
+                t.zero_()
+
     def load_reference_state(self, sd, strict=True):
+        self._drop_fp8_history()
         return self.arena.load_state(sd, strict)
 
     def save_model(self, path):
         torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, path)
 
     def load_model(self, path):
+        self._drop_fp8_history()
         self.arena.load_state(torch.load(path, map_location="cpu", weights_only=True))
 
     def load_pretrained_encoder(self, path):
@@ -145,6 +155,7 @@ class NBestSTCModel(nn.Module):
             if not found:
                 raise FileNotFoundError("no model.safetensors / pytorch_model.bin under %s" % path)
             path = found[0]
+        self._drop_fp8_history()
         if path.endswith(".safetensors"):
             from safetensors.torch import load_file
             raw = load_file(path, device="cpu")
@@ -292,11 +303,13 @@ class NBestSTCModel(nn.Module):
     # ---- one training forward + backward (n_best_asr_bert.py:249-264) ---------------------------
     def forward_backward(self, input_ids, labels_f, seg_ids=None, trans_input_ids=None, trans_seg_ids=None,
                          add_l2_loss=False, mse_grad_scale=1.0, chunks=None, on_chunk_done=None, need_grad=True,
-                         accumulate=False):
+                         accumulate=False, encoder_grad_scale=1.0):
         """Returns dict(top, bott, final, loss_parts[4] (device), asr_cls, trans_cls).  Gradients of the sum
         BCE(final) + BCE(top) + mean-CE (+ MSE) are left in ``arena.g``.  The transcript pass runs only
         when its output is used (--add_l2_loss); the reference computes and discards it otherwise (Q4).
-        ``accumulate``: add to the gradients already in ``arena.g`` (gradient accumulation) instead of overwriting them."""
+        ``accumulate``: add to the gradients already in ``arena.g`` (gradient accumulation) instead of overwriting them.
+        ``encoder_grad_scale``: multiplies the gradient entering the encoder (the CLS rows) - a loss-scaling knob; the tests use it to
+        make every gradient amax of the fp8 backward jump between two consecutive steps."""
         train = self.training
         B, S = input_ids.shape
         H = self.cfg.hidden_size
@@ -314,6 +327,10 @@ class NBestSTCModel(nn.Module):
             dt = torch.empty(B, H, dtype=torch.float32, device=self.device) if need_grad else None
             mse = hb.cls_mse(ha, S * H, ht, St * H, B, H, dcls, dt, grad_scale=mse_grad_scale)
             loss[3:4].copy_(mse)
+        if need_grad and encoder_grad_scale != 1.0:
+            dcls.mul_(encoder_grad_scale)
+            if dt is not None:
+                dt.mul_(encoder_grad_scale)
         if need_grad:
             if pt is not None:
                 # transcript pass first (whole stack, no overlap hooks), then the ASR pass accumulates on top

@@ -62,6 +62,26 @@ def model_state(cfg, labels, seed=999, std=0.02, head_std=0.05):
     return sd
 
 
+def pretrained_like(sd, cfg, seed=999, n_dims=6, ln_gain=10.0, col_gain=20.0):
+    """Give a random-init state the statistics that set pretrained BERT / XLM-R apart from std-0.02 noise: a handful of OUTLIER
+    feature dimensions - LayerNorm gains x ``ln_gain`` there (every LayerNorm of the stack), the same columns of the word /
+    position tables and of the dense-output biases x ``col_gain``.  Those dimensions then carry activations one to two orders
+    of magnitude above the rest through the whole residual stream: the distribution the unit-scale e4m3 activations, the 8-bit
+    GELU' and the per-tensor gradient scales of the fp8 mode have to survive.  In place; returns the outlier dimensions."""
+    H = cfg.hidden_size
+    dims = np.sort(_rng(seed, "outlier-dims").choice(H, size=n_dims, replace=False))
+    for n, v in sd.items():
+        if not n.startswith("bert_encoder."):
+            continue
+        if n.endswith("LayerNorm.weight"):
+            v[dims] *= ln_gain
+        elif n.endswith(("word_embeddings.weight", "position_embeddings.weight")):
+            v[:, dims] *= col_gain
+        elif n.endswith(("attention.output.dense.bias", ".output.dense.bias")) and v.shape[0] == H:
+            v[dims] *= col_gain
+    return dims
+
+
 def nbest_batch(cfg, labels, B, S, n_best=5, seed=999, ragged=False, trans_len=None):
     """Synthetic padded hypothesis batch.  Returns dict of int64/float32 ndarrays:
     ids[B,S], seg[B,S], labels[B,n_bottom] (+ tids/tseg [B,trans_len] when trans_len)."""

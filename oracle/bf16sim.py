@@ -55,19 +55,20 @@ def _q8(g):
 
 
 class _GeluStore(torch.autograd.Function):
-    """FFN-up epilogue: hact = bf16(gelu(u)), stash q8(gelu'(u)); backward du = bf16(dh * gelu')"""
+    """FFN-up epilogue: hact = bf16(gelu(u)), stash q8(gelu'(u)); backward du = bf16(dh * gelu').  ``q8`` False: gelu' kept in
+    bf16 instead - the plain bf16-storage implementation the 8-bit form is measured against (make_golden.py)."""
 
     @staticmethod
-    def forward(ctx, u):
+    def forward(ctx, u, q8=True):
         cdf = 0.5 * (1.0 + torch.erf(u * (1.0 / math.sqrt(2.0))))
         pdf = torch.exp(-0.5 * u * u) * (1.0 / math.sqrt(2.0 * math.pi))
-        ctx.save_for_backward(_q8(cdf + u * pdf))
+        ctx.save_for_backward(_q8(cdf + u * pdf) if q8 else _r(cdf + u * pdf))
         return _r(u * cdf)
 
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
-        return _r(g * d)
+        return _r(g * d), None
 
 
 class _AttnCore(torch.autograd.Function):
@@ -100,10 +101,11 @@ def _e4m3(x):
     return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
 
 
-def _fp8_scale(t):
-    """per-tensor power-of-two scale of the fp8 copies: 2^floor(log2(224 / max|t|)) (common.h fp8_scale_of)"""
+def _fp8_scale(t, target=224.0):
+    """per-tensor power-of-two scale of the fp8 copies: 2^floor(log2(target / max|t|)); weights map their maximum to 224
+    (common.h fp8_scale_of), gradients to 56 = 8 x headroom under the one-step-old amax (fp8_gscale_of)"""
     a = t.abs().max()
-    return 2.0 ** torch.floor(torch.log2(224.0 / a)) if a > 0 else torch.tensor(1.0)
+    return 2.0 ** torch.floor(torch.log2(target / a)) if a > 0 else torch.tensor(1.0)
 
 
 class _Fp8Linear(torch.autograd.Function):
@@ -128,7 +130,7 @@ class _Fp8Linear(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         gw = g2
         if ctx.bwd8:
-            sg = _fp8_scale(g2)
+            sg = _fp8_scale(g2, 56.0)
             gw = _e4m3(g2 * sg) / sg
             dx = gw.view_as(g) @ wd
         else:
@@ -162,7 +164,7 @@ def _ln(x, mod):
     return F.layer_norm(x, (x.shape[-1],), mod.weight, mod.bias, mod.eps)
 
 
-def encode(enc, ids, seg, fp8=False, fp8_bwd=False):
+def encode(enc, ids, seg, fp8=False, fp8_bwd=False, q8=True):
     """oracle.encoder.OracleEncoder.forward with bf16 storage (dropout must be off: parity runs use p = 0); ``fp8``: the
     four forward GEMMs of every layer as the "fp8w" path runs them (e4m3 operands, the Q|K|V projection as ONE [3H, H]
     matrix with one scale), ``fp8_bwd``: their four dgrads in fp8 as well (see _Fp8Linear)"""
@@ -201,20 +203,20 @@ def encode(enc, ids, seg, fp8=False, fp8_bwd=False):
         else:
             r1 = ract(F.linear(ctx, rw(ao.dense.weight), ao.dense.bias) + x)
             x1 = ract(_ln(r1, ao.LayerNorm))
-            hact = _GeluStore.apply(F.linear(x1, rw(lyr.intermediate.dense.weight), lyr.intermediate.dense.bias))
+            hact = _GeluStore.apply(F.linear(x1, rw(lyr.intermediate.dense.weight), lyr.intermediate.dense.bias), q8)
             r2 = ract(F.linear(hact, rw(lyr.output.dense.weight), lyr.output.dense.bias) + x1)
         x = ract(_ln(r2, lyr.output.LayerNorm))
     return x[:, 0, :]
 
 
-def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, fp8=False, fp8_bwd=False):
+def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, fp8=False, fp8_bwd=False, q8=True):
     """oracle.model.OracleModel.forward (classifier_input_type 'asr') on the bf16-storage encoder; heads in fp32"""
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             assert m.p == 0.0 or not model.training
     if model.family == "xlm-roberta":
         seg_ids = trans_seg_ids = None
-    asr_cls = encode(model.bert_encoder, input_ids, seg_ids, fp8, fp8_bwd)
-    trans_cls = encode(model.bert_encoder, trans_input_ids, trans_seg_ids, fp8, fp8_bwd) if trans_input_ids is not None else None
+    asr_cls = encode(model.bert_encoder, input_ids, seg_ids, fp8, fp8_bwd, q8)
+    trans_cls = encode(model.bert_encoder, trans_input_ids, trans_seg_ids, fp8, fp8_bwd, q8) if trans_input_ids is not None else None
     top, bottoms, final = model.clf(asr_cls)
     return top, bottoms, final, asr_cls, trans_cls

@@ -34,6 +34,8 @@ def case_inputs(meta, labels):
     mk = {"xlm-roberta": ncfg.xlmr_base, "xlm-roberta-large": ncfg.xlmr_large, "bert": ncfg.bert_base}[meta["family"]]
     cfg = mk(num_hidden_layers=meta["L"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     sd = synth.model_state(cfg, labels, seed=meta["seed"])
+    if meta.get("outliers"):
+        synth.pretrained_like(sd, cfg, seed=meta["seed"])
     batch = synth.nbest_batch(cfg, labels, meta["B"], meta["S"], n_best=meta["n_best"], seed=meta["seed"],
                               ragged=True, trans_len=meta["St"])
     return cfg, sd, batch

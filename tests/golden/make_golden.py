@@ -113,8 +113,14 @@ def main():
         # The reference hard-codes fea_dim = 768 (models/model.py:30, quirk Q7) and cannot build heads on a 1024-wide
         # encoder: the generator swaps in the reference's OWN HierarchicalClassifier constructed with input_dim = 1024.
         dict(name="xlmrL_L4_S256", family="xlm-roberta-large", L=4, B=2, S=256, St=64, n_best=10, add_l2=True, seg=True, seed=17),
+        # "pretrained-like" statistics (synth.pretrained_like): six outlier feature dimensions - LayerNorm gains x 10, the same
+        # columns of the word / position tables and dense-output biases x 20 - through 4 layers.  What random-init std-0.02 weights
+        # never show the bf16 / fp8 paths: activations two orders of magnitude apart inside one row.
+        dict(name="bert_L4_outliers", family="bert", L=4, B=3, S=96, St=24, n_best=5, add_l2=True, seg=True, seed=18, outliers=True),
     ]
     only = [a for a in sys.argv[1:] if a.startswith("case_")]
+    if sys.argv[1:] == ["rest"]:
+        cases = []
     for c in cases:
         if only and "case_" + c["name"] not in only:
             continue
@@ -122,6 +128,7 @@ def main():
     if only:
         return
     run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim)
+    run_traj_case()
     run_coverage_case()
     run_observe_case()
     run_xlmr_input_case()
@@ -133,6 +140,8 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
     mk = {"xlm-roberta": ncfg.xlmr_base, "xlm-roberta-large": ncfg.xlmr_large, "bert": ncfg.bert_base}[c["family"]]
     cfg = mk(num_hidden_layers=c["L"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     sd_np = synth.model_state(cfg, labels, seed=c["seed"])
+    if c.get("outliers"):
+        print("   outlier feature dimensions:", synth.pretrained_like(sd_np, cfg, seed=c["seed"]).tolist())
     batch = synth.nbest_batch(cfg, labels, c["B"], c["S"], n_best=c["n_best"], seed=c["seed"], ragged=True,
                               trans_len=c["St"])
     ids, seg = torch.from_numpy(batch["ids"]), torch.from_numpy(batch["seg"])
@@ -204,8 +213,8 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
         assert d <= tol, (what, d)
     chk(otop, top, 2e-6, "top_scores")
     chk(ofin, final, 2e-6, "final_scores")
-    chk(oasr, asr_cls, 2e-5, "asr_cls")
-    chk(otr, trans_cls, 2e-5, "trans_cls")
+    chk(oasr, asr_cls, 2e-5 * max(1.0, asr_cls.abs().max().item() / 4.0), "asr_cls")      # CLS rows are O(4) (O(100) with outlier gains)
+    chk(otr, trans_cls, 2e-5 * max(1.0, trans_cls.abs().max().item() / 4.0), "trans_cls")
     chk(ototal, total, 2e-4 * max(1.0, abs(total.item())), "total_loss")
     assert abs(orec - rec) < 1e-4 * max(1, abs(rec))
     for n, p in om.named_parameters():
@@ -215,45 +224,72 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
             assert (p.grad - grads[n]).abs().max().item() <= 5e-5 * max(1.0, grads[n].abs().max().item()), n
         else:
             assert p.grad is None or p.grad.abs().max() == 0, n
-    # ---------------- bf16-storage leg of the oracle: the noise floor of this case ----------------
+    # ---------------- storage legs of the oracle: the noise floors of this case ----------------
+    #   floor/    bf16 storage as the HIP bf16 path keeps it (gelu' in 8-bit fixed point)          -> bar of the bf16 path
+    #   floorb/   plain bf16 storage (gelu' in bf16): what the 8-bit gelu' is measured against      -> asserted here, committed
+    #   floor8/   "fp8w": e4m3 operands of all twelve GEMMs of a layer (bf16sim fp8=True, fp8_bwd=True) -> bar of the fp8w path
     from oracle import bf16sim
+    import zlib
     ograds = {n: p.grad for n, p in om.named_parameters()}
-    for p in om.parameters():
-        p.grad = None
-    stop, sbot, sfin, sasr, str_ = bf16sim.forward(om, ids, tids, seg_ids=seg_in, trans_seg_ids=tseg)
-    _, stotal, _ = ostc.total_loss(stop, sbot, sfin, y, t2b, ostc.bottom2top_matrix(t2b), sasr, str_, c["add_l2"])
-    stotal.backward()
-    sgrads = {n: p.grad.detach() for n, p in om.named_parameters() if p.grad is not None}
-    for n, p in om.named_parameters():
-        p.grad = ograds[n]
-
     fx_extra = {}
 
     def floor(a, b):
         d = (a.detach().float() - b.detach().float())
         return np.array([d.abs().max().item(), d.pow(2).mean().sqrt().item()])
     sl = lambda g: g.reshape(-1, g.shape[-1])[:8, :64] if g.dim() > 1 else g[:64]
-    fl = {"floor/top": floor(stop, top), "floor/final": floor(sfin, final),
-          "floor/bottoms": floor(torch.cat([sbot["lin_%d" % t] for t in labels.multi], 1),
-                                 torch.cat([bottoms["lin_%d" % t] for t in labels.multi], 1)),
-          "floor/asr_cls": floor(sasr, asr_cls), "floor/trans_cls": floor(str_, trans_cls),
-          "floor/loss_total": np.array([abs(stotal.item() - total.item()) / abs(total.item())])}
-    import zlib
-    for n, g in grads.items():
-        gn = max(g.norm().item(), 1e-30)
-        fl["floor/gnorm/" + n] = np.array([abs(sgrads[n].norm().item() - g.norm().item()) / gn])
-        # noise-to-signal of the bf16-storage leg, ||g_sim - g_ref|| / ||g_ref||: by Cauchy-Schwarz it also bounds the
-        # relative norm error; and 512 sampled elements per tensor (indices from a name-keyed legacy numpy stream) so the
-        # GPU test can estimate the SAME statistic for the HIP path without the full reference gradient
-        fl["floor/ns/" + n] = np.array([(sgrads[n] - g).norm().item() / gn])
-        if "word_embeddings" not in n:
-            idx = torch.from_numpy(np.random.RandomState(zlib.crc32(n.encode()) & 0x7FFFFFFF).randint(0, g.numel(), size=512))
-            ref_s, sim_s = g.flatten()[idx], sgrads[n].flatten()[idx]
-            fx_extra["samp/" + n] = ref_s.numpy().astype(np.float32)
-            fl["floor/samp/" + n] = np.array([(sim_s - ref_s).pow(2).mean().sqrt().item(), ref_s.pow(2).mean().sqrt().item()])
-    print("   bf16-storage oracle vs reference: top %.2e final %.2e bottoms %.2e asr_cls %.2e loss rel %.2e, worst grad-norm rel %.2e" % (
-        fl["floor/top"][0], fl["floor/final"][0], fl["floor/bottoms"][0], fl["floor/asr_cls"][0], fl["floor/loss_total"][0],
-        max(v[0] for k, v in fl.items() if k.startswith("floor/gnorm/") and not k.endswith("key.bias"))))
+
+    def run_leg(prefix, **kw):
+        for p in om.parameters():
+            p.grad = None
+        stop, sbot, sfin, sasr, str_ = bf16sim.forward(om, ids, tids, seg_ids=seg_in, trans_seg_ids=tseg, **kw)
+        _, stotal, _ = ostc.total_loss(stop, sbot, sfin, y, t2b, ostc.bottom2top_matrix(t2b), sasr, str_, c["add_l2"])
+        stotal.backward()
+        sg = {n: p.grad.detach() for n, p in om.named_parameters() if p.grad is not None}
+        f = {prefix + "top": floor(stop, top), prefix + "final": floor(sfin, final),
+             prefix + "bottoms": floor(torch.cat([sbot["lin_%d" % t] for t in labels.multi], 1),
+                                       torch.cat([bottoms["lin_%d" % t] for t in labels.multi], 1)),
+             prefix + "asr_cls": floor(sasr, asr_cls), prefix + "trans_cls": floor(str_, trans_cls),
+             prefix + "loss_total": np.array([abs(stotal.item() - total.item()) / abs(total.item())])}
+        for n, g in grads.items():
+            gn = max(g.norm().item(), 1e-30)
+            f[prefix + "gnorm/" + n] = np.array([abs(sg[n].norm().item() - g.norm().item()) / gn])
+            # noise-to-signal of the leg, ||g_sim - g_ref|| / ||g_ref||: by Cauchy-Schwarz it also bounds the relative norm
+            # error; and 512 sampled elements per tensor (indices from a name-keyed legacy numpy stream) so the GPU test can
+            # estimate the SAME statistic for the HIP path without the full reference gradient
+            f[prefix + "ns/" + n] = np.array([(sg[n] - g).norm().item() / gn])
+            if "word_embeddings" not in n:
+                idx = torch.from_numpy(np.random.RandomState(zlib.crc32(n.encode()) & 0x7FFFFFFF).randint(0, g.numel(), size=512))
+                ref_s, sim_s = g.flatten()[idx], sg[n].flatten()[idx]
+                fx_extra["samp/" + n] = ref_s.numpy().astype(np.float32)
+                f[prefix + "samp/" + n] = np.array([(sim_s - ref_s).pow(2).mean().sqrt().item(), ref_s.pow(2).mean().sqrt().item()])
+                if c.get("outliers"):
+                    # heavy-tailed gradients (a few rows / columns carry the outlier dimensions): the rms over 512 samples is set
+                    # by the two or three giant elements a sample happens to contain, so this case also commits a robust
+                    # statistic of the same samples - the 90th percentile of the absolute error
+                    f[prefix + "sampq/" + n] = np.array([torch.quantile((sim_s - ref_s).abs(), 0.9).item()])
+        print("   %-7s leg vs reference: top %.2e final %.2e bottoms %.2e asr_cls %.2e loss rel %.2e, worst grad-norm rel %.2e" % (
+            prefix, f[prefix + "top"][0], f[prefix + "final"][0], f[prefix + "bottoms"][0], f[prefix + "asr_cls"][0],
+            f[prefix + "loss_total"][0],
+            max(v[0] for k, v in f.items() if k.startswith(prefix + "gnorm/") and not k.endswith("key.bias"))))
+        return f, sg
+
+    fl, sgrads = run_leg("floor/")
+    flb, sgrads_b = run_leg("floorb/", q8=False)
+    fl8, sgrads_8 = run_leg("floor8/", fp8=True, fp8_bwd=True)
+    for n, p in om.named_parameters():
+        p.grad = ograds[n]
+    # the 8-bit gelu' must not cost gradient accuracy against plain bf16 storage.  Measured over the eight cases: the per-matrix
+    # noise-to-signal ratio q8 leg / bf16-gelu' leg has a median of 0.99 .. 1.03 and a maximum of 1.02 .. 1.11 - and the worst
+    # matrices are query / key weights of early layers, not the FFN matrices gelu' multiplies: the two legs are two different draws
+    # of the same rounding noise (one changed rounding anywhere re-draws everything downstream), not a systematic loss.  Bars:
+    # median <= 1.05, maximum <= 1.2.  Both legs are committed (floor/ns, floorb/ns); tests/test_oracle_golden.py re-checks them.
+    dense = [n for n in grads if n.startswith("bert_encoder.encoder.") and grads[n].numel() >= 4096]
+    ratios = sorted((fl["floor/ns/" + n][0] / max(flb["floorb/ns/" + n][0], 1e-30), n) for n in dense)
+    print("   8-bit gelu' vs bf16 gelu': gradient noise-to-signal ratio over %d matrices: median %.3f, max %.3f (%s)" % (
+        len(ratios), ratios[len(ratios) // 2][0], ratios[-1][0], ratios[-1][1][-40:]))
+    assert ratios[len(ratios) // 2][0] <= 1.05 and ratios[-1][0] <= 1.2, ratios[-5:]
+    fl.update({k: v for k, v in flb.items() if not k.startswith(("floorb/samp/", "floorb/gnorm/"))})
+    fl.update(fl8)
 
     oopt = OracleBertAdam(list(om.named_parameters()), lr=5e-4, bert_lr=3e-5, warmup=0.1, t_total=t_total)
     oopt.step()
@@ -290,6 +326,7 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
         g = grads[n]
         fx["grad/" + n] = g.reshape(-1, g.shape[-1])[:8, :64].numpy() if g.dim() > 1 else g[:64].numpy()
         fl["floor/grad/" + n] = floor(sl(sgrads[n]), sl(g))
+        fl["floor8/grad/" + n] = floor(sl(sgrads_8[n]), sl(g))
         d = after[n] - before[n]
         fx["delta/" + n] = d.reshape(-1, d.shape[-1])[:8, :64].numpy() if d.dim() > 1 else d[:64].numpy()
     # rows of the word-embedding gradient that are touched (scatter-add parity)
@@ -298,6 +335,8 @@ def run_case(c, labels, t2b, idx2label, memory, ref_model, ref_optim, ns):
     fx["wordgrad_vals"] = grads["bert_encoder.embeddings.word_embeddings.weight"][used, :64].numpy()
     fl["floor/wordgrad"] = floor(sgrads["bert_encoder.embeddings.word_embeddings.weight"][used, :64],
                                  grads["bert_encoder.embeddings.word_embeddings.weight"][used, :64])
+    fl["floor8/wordgrad"] = floor(sgrads_8["bert_encoder.embeddings.word_embeddings.weight"][used, :64],
+                                  grads["bert_encoder.embeddings.word_embeddings.weight"][used, :64])
     fx.update(fl)
     fx.update(fx_extra)
     np.savez_compressed(os.path.join(HERE, "case_%s.npz" % c["name"]), **fx)
@@ -392,6 +431,86 @@ def run_text_case(labels, t2b, idx2label, memory, ref_model, ref_optim):
     fx["label2idx"] = np.array(json.dumps({k: int(v) for k, v in memory["label2idx"].items()}))
     np.savez_compressed(os.path.join(HERE, "case_text.npz"), **fx)
     print("   wrote case_text.npz, valid_head.txt, text_vocab.json")
+
+
+def run_traj_case(epochs=6, n_train=384, n_held=128, BS=16, lr=1e-3, bert_lr=2e-4, seeds=(23, 24, 25, 26, 27, 28, 29, 30)):
+    """F1 TRAJECTORIES of the reference loop on real text: the stand-in for "DSTC2 F1 within 0.2 pt" that can be produced offline
+    (no pretrained weights, no train / test split: only `valid` ships).  /root/reference n_best_asr_bert.py train_epoch /
+    eval_epoch (exec'd text slice :145-389; F1 by utils/fscore.py) for ``epochs`` epochs over the first ``n_train`` lines of the
+    shipped valid split, evaluated after every epoch on the next ``n_held`` lines (never trained on); 2-layer bert on the
+    committed WordPiece vocabulary, dropout 0, BertAdam (warm-up 0.1, t_total = all steps), fixed batch order, fp32 CPU.
+    One run per initialisation seed: 144 Adam steps amplify a 1e-6 difference into a different trajectory (the fp32 HIP path
+    follows the reference to 4 digits through the first epoch and then drifts by 1-2 F1 points like any other draw), so the
+    comparable quantity is the MEAN over seeds - as the reference's README reports its own F1 (mean of 5 seeds, README.md:77).
+    Committed: per seed and epoch (loss, P, R, F, Acc) of both parts.  Data fixture: valid_512.txt (inputs of this case)."""
+    print("== trajectory case (reference loop, %d seeds x %d epochs, %d train / %d held-out utterances)" % (len(seeds), epochs, n_train, n_held))
+    import io, contextlib, warnings
+    import utils.bert_xlnet_inputs as ref_inputs
+    import utils.dataset.tod_asr_util as ref_data
+    import utils.STC_util as ref_stc
+    import utils.fscore as ref_fscore
+    import models.model as ref_model
+    import models.optimization as ref_optim
+    from nbest_amd import inputs as my_inputs
+    memory = torch.load(os.path.join(REF, "dstc2_data/processed_data/raw/memory.pt"))
+    memory["bottom2top_mat"] = ref_stc.reverse_top2bottom(memory["top2bottom_dict"])
+    t2b = {int(k): [int(x) for x in v] for k, v in memory["top2bottom_dict"].items()}
+    labels = ncfg.LabelSpace(t2b, [memory["idx2label"][i] for i in range(len(memory["idx2label"]))])
+    lines = open(os.path.join(REF, "dstc2_data/processed_data/raw/valid")).read().split("\n")[:n_train + n_held]
+    with open(os.path.join(HERE, "valid_512.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    vocab = json.load(open(os.path.join(HERE, "text_vocab.json")))
+    tok = my_inputs.WordPieceTokenizer(vocab)
+    with contextlib.redirect_stdout(io.StringIO()):
+        data = ref_data.read_wcn_data(os.path.join(HERE, "valid_512.txt"))
+    tr = tuple(list(x[:n_train]) for x in data)
+    he = tuple(list(x[n_train:n_train + n_held]) for x in data)
+    src = open(os.path.join(REF, "n_best_asr_bert.py")).read()
+    body = src[src.index("def cal_ce_loss"):src.index("def train(model")]
+    ns = dict(np=np, torch=torch, nn=nn, update_f1=ref_fscore.update_f1, compute_f1=ref_fscore.compute_f1,
+              prepare_inputs_for_roberta=ref_inputs.prepare_inputs_for_roberta, convert_labels=ref_stc.convert_labels,
+              onehot_to_scalar=ref_stc.onehot_to_scalar, EpochInfoCollector=ref_data.EpochInfoCollector)
+    exec(compile(body, "n_best_asr_bert.py[145:389]", "exec"), ns)
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=len(vocab), hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    steps = (n_train + BS - 1) // BS
+    t_total = epochs * steps
+    all_tr, all_he = [], []
+    for seed in seeds:
+        sd_np = synth.model_state(cfg, labels, seed=seed)
+        enc = hf_encoder(cfg)
+        opt = types.SimpleNamespace(pretrained_model=enc, dropout=0.0, device=torch.device("cpu"), score_util="pp", sent_repr="bin_sa_cls",
+                                    cls_type="stc", top2bottom_dict=memory["top2bottom_dict"], label_vocab_size=labels.n_bottom,
+                                    pre_trained_model="bert", tod_pre_trained_model=None, without_system_act=False, add_l2_loss=False,
+                                    add_segment_ids=True, tokenizer=tok, n_accum_steps=1, optim_choice="bertadam", max_norm=5.0,
+                                    ontology=None, testing=False, class_loss_function=nn.BCELoss(reduction="sum"),
+                                    ce_loss_function=nn.NLLLoss(reduction="sum"), mse_loss_function=nn.MSELoss())
+        model = ref_model.make_model(opt)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+        groups = [dict(params=p, weight_decay=0.0 if any(nd in n for nd in no_decay) else 0.01,
+                       lr=bert_lr if "bert_encoder" in n else lr) for n, p in named]
+        opt.optimizer = ref_optim.BertAdam(groups, lr=lr, warmup=0.1, t_total=t_total)
+        tr_loader = ref_data.prepare_wcn_dataloader(tr, memory, BS, None, opt.device, shuffle_flag=False)
+        he_loader = ref_data.prepare_wcn_dataloader(he, memory, BS, None, opt.device, shuffle_flag=False)
+        rows_tr, rows_he = [], []
+        for ep in range(epochs):
+            with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                l, (p, r, f), a = ns["train_epoch"](model, tr_loader, opt, memory)
+                el, (ep_, er, ef), ea, _ = ns["eval_epoch"](model, he_loader, opt, memory, io.StringIO(), io.StringIO())
+            rows_tr.append([l, p, r, f, a])
+            rows_he.append([el, ep_, er, ef, ea])
+        print("   seed %d  final: train loss %8.4f F %6.2f Acc %6.2f | held-out loss %8.4f P %6.2f R %6.2f F %6.2f Acc %6.2f   (held-out F by epoch: %s)" % (
+            seed, *[rows_tr[-1][i] for i in (0, 3, 4)], *rows_he[-1], " ".join("%.1f" % r[3] for r in rows_he)))
+        all_tr.append(rows_tr)
+        all_he.append(rows_he)
+    hf = np.array(all_he)[:, -1, 3]
+    print("   final held-out F1 over %d seeds: mean %.2f, std %.2f, min %.2f, max %.2f" % (len(seeds), hf.mean(), hf.std(ddof=1), hf.min(), hf.max()))
+    np.savez_compressed(os.path.join(HERE, "case_traj.npz"), train=np.array(all_tr), held=np.array(all_he),
+                        meta=np.array(json.dumps(dict(epochs=epochs, n_train=n_train, n_held=n_held, batch=BS, lr=lr, bert_lr=bert_lr,
+                                                      seeds=list(seeds), t_total=t_total, L=2))))
+    print("   wrote case_traj.npz, valid_512.txt")
 
 
 def run_coverage_case():
@@ -532,5 +651,8 @@ if __name__ == "__main__":
         run_xlmr_input_case()
     elif sys.argv[1:] == ["observe"]:
         run_observe_case()
+    elif sys.argv[1:2] == ["traj"]:
+        kw = dict(a.split("=") for a in sys.argv[2:])
+        run_traj_case(**{k: (float(v) if "lr" in k else tuple(int(x) for x in v.split(",")) if k == "seeds" else int(v)) for k, v in kw.items()})
     else:
         main()          # `make_golden.py case_<name> ...` regenerates only the named encoder cases

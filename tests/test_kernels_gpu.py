@@ -476,9 +476,14 @@ def test_wgrad_fp8_transposed_reads(M, N, K):
     ref = dY8.float().t() @ X8.float()
     got = hb.wgrad_fp8(dY8.view(torch.uint8), X8.view(torch.uint8), M, N, K)
     close("wgrad_fp8[%dx%d K=%d]" % (M, N, K), got, ref, 1e-4)
-    amax = torch.tensor([3.0], device=DEV).view(torch.int32)             # scale 2^floor(log2(224/3)) = 64
+    amax = torch.tensor([3.0], device=DEV).view(torch.int32)             # gradient scale 2^floor(log2(56/3)) = 16 (common.h fp8_gscale_of)
     got2 = hb.wgrad_fp8(dY8.view(torch.uint8), X8.view(torch.uint8), M, N, K, a_amax=amax, out=got.clone(), accumulate=True)
-    close("wgrad_fp8 scaled + accumulate", got2, ref * (1 + 1 / 64.0), 1e-4)
+    close("wgrad_fp8 scaled + accumulate", got2, ref * (1 + 1 / 16.0), 1e-4)
+    # a zero / non-finite amax (nothing recorded yet, an overflowed pass) means scale 1, not 0 or inf
+    for bad in (0.0, float("inf"), float("nan"), 1e-40):
+        amax = torch.tensor([bad], device=DEV).view(torch.int32)
+        got3 = hb.wgrad_fp8(dY8.view(torch.uint8), X8.view(torch.uint8), M, N, K, a_amax=amax)
+        close("wgrad_fp8 amax=%r -> scale 1" % bad, got3, ref, 1e-4)
 
 
 def test_transposed_weight_copies():

@@ -76,6 +76,41 @@ def test_bf16_storage_leg_reproduces_committed_floor(labels):
     assert 1e-4 < (stop - top).abs().max().item() < 2e-2
 
 
+ALL_CASES = ["bert_L2", "bert_L2_noseg", "xlmr_L2", "bert_L12", "bert_L12_S256", "xlmr_L12", "xlmrL_L4_S256", "bert_L4_outliers"]
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_8bit_gelu_derivative_costs_no_gradient_accuracy(name):
+    """The bf16 path keeps gelu'(u) for the backward in 8-bit fixed point (csrc/common.h gd_pack4) and its parity bar is the
+    noise floor of an oracle leg with the SAME 8-bit rounding (`floor/`).  So that the bar cannot hide a loss against plain bf16
+    storage, every case also commits the leg with gelu' kept in bf16 (`floorb/`): per encoder-layer matrix the gradient
+    noise-to-signal of the 8-bit leg must not exceed the bf16 leg's by more than the draw-to-draw spread of the two legs
+    (median over the matrices within 5 %, worst matrix within 20 %), and the score floors must agree."""
+    meta, z = load_case(name)
+    dense = [k[len("floor/ns/"):] for k in z.files if k.startswith("floor/ns/bert_encoder.encoder.") and k.endswith(".weight")
+             and "LayerNorm" not in k]
+    assert len(dense) >= 12
+    ratios = sorted(float(z["floor/ns/" + n][0]) / max(float(z["floorb/ns/" + n][0]), 1e-30) for n in dense)
+    assert ratios[len(ratios) // 2] <= 1.05 and ratios[-1] <= 1.2, (ratios[len(ratios) // 2], ratios[-1])
+    for k in ("top", "final", "bottoms"):
+        assert float(z["floor/" + k][0]) <= 1.25 * float(z["floorb/" + k][0]) + 1e-6, k
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_fp8_floor_is_committed_for_every_case(name):
+    """every reference-generated case carries the fp8 leg's floors (scores, CLS rows, loss, per-tensor gradient statistics): the
+    bar the fp8w path (BASELINE configs[4]) is held to in tests/test_model_gpu.py - and they are fp8-sized: above the bf16 floor,
+    far below the signal"""
+    meta, z = load_case(name)
+    for k in ("top", "final", "bottoms", "asr_cls", "loss_total"):
+        assert ("floor8/" + k) in z.files
+        assert float(z["floor8/" + k][0]) >= 0.8 * float(z["floor/" + k][0]), k
+    assert float(z["floor8/top"][0]) < 0.15
+    n8 = [k for k in z.files if k.startswith("floor8/ns/")]
+    assert len(n8) == len([k for k in z.files if k.startswith("floor/ns/")]) > 20
+    assert any(k.startswith("floor8/samp/") for k in z.files) and "floor8/wordgrad" in z.files
+
+
 def test_reference_known_answers(labels):
     from oracle import stc
     kat = json.load(open(os.path.join(GOLDEN, "kat.json")))

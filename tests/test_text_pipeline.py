@@ -122,6 +122,64 @@ def test_utterance_longer_than_256_tokens_runs_untruncated(labels):
     print("long-utterance epoch losses (train, eval):", {str(k): v for k, v in res.items()})
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8w"])
+def test_f1_trajectory_tracks_reference_loop(dtype, labels):
+    """F1 TRAJECTORIES on real text against the reference's own loop (fixture tests/golden/case_traj.npz: /root/reference
+    train_epoch / eval_epoch / utils/fscore.py, 8 initialisation seeds x 6 epochs over valid[:384], evaluated after every epoch on
+    valid[384:512], which is never trained on; 2-layer bert, dropout 0, fixed batch order).  The offline stand-in for the
+    north_star's "DSTC2 F1 within 0.2 pt": pretrained weights and the train / test splits do not exist here.
+
+    What can be asserted, and what was measured (profiles/r03_f1_trajectory.log):
+      * fp32 path, first epoch of every seed: loss / P / R / F / Acc of both parts equal the reference's (4 digits of the loss,
+        identical label decisions) - the loop, the loss record and the F1 bookkeeping are the reference's;
+      * after that, 144 Adam steps amplify a 1e-6 difference into a different trajectory: the fp32 HIP path ends 1-2 F1 points away
+        from the reference run of the same seed, like any other draw.  So the comparable quantity is the MEAN over the seeds (the
+        reference's README reports its F1 the same way): final held-out F1 of every dtype within 1.5 pt of the reference's mean
+        (one held-out label decision = 0.35 pt; the standard error of an 8-seed mean is ~0.5 pt - 0.2 pt is below what 128 held-out
+        utterances can resolve), final train F1 within 1.5 pt."""
+    from nbest_amd.model import NBestSTCModel
+    from nbest_amd.optim import HipBertAdam
+    z = np.load(os.path.join(GOLDEN, "case_traj.npz"))
+    meta = json.loads(str(z["meta"]))
+    vocab = json.load(open(os.path.join(GOLDEN, "text_vocab.json")))
+    data = trainer.read_wcn_data(os.path.join(GOLDEN, "valid_512.txt"))
+    nt, nh = meta["n_train"], meta["n_held"]
+    tr = tuple(list(x[:nt]) for x in data)
+    he = tuple(list(x[nt:nt + nh]) for x in data)
+    cfg = ncfg.bert_base(num_hidden_layers=meta["L"], vocab_size=len(vocab), hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cd = {"f32": torch.float32, "bf16": torch.bfloat16, "fp8w": torch.bfloat16}[dtype]
+    label2idx = json.loads(str(np.load(os.path.join(GOLDEN, "case_text.npz"))["label2idx"]))
+    memory = dict(label2idx=label2idx, idx2label=labels.idx2label)
+    fin_tr, fin_he = [], []
+    for si, seed in enumerate(meta["seeds"]):
+        m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=cd, dropout=0.0, fp8_forward=(dtype == "fp8w"))
+        m.load_reference_state(synth.model_state(cfg, labels, seed=seed))
+        opt = types.SimpleNamespace(batchSize=meta["batch"], tokenizer=inputs.WordPieceTokenizer(vocab), pre_trained_model="bert",
+                                    tod_pre_trained_model=None, without_system_act=False, add_l2_loss=False, add_segment_ids=True)
+        opt.optimizer = HipBertAdam(m, lr=meta["lr"], bert_lr=meta["bert_lr"], warmup=0.1, t_total=meta["t_total"])
+        split_tr, split_he = trainer.EncodedSplit(tr, opt, memory), trainer.EncodedSplit(he, opt, memory)
+        hist = []
+        for ep in range(meta["epochs"]):
+            l, (p, r, f), a = trainer.train_epoch(m, split_tr, opt, memory, shuffle=False)
+            el, (ep_, er, ef), ea, _ = trainer.eval_epoch(m, split_he, opt, memory)
+            hist.append(ef)
+            rt, rh = z["train"][si][ep], z["held"][si][ep]
+            if dtype == "f32" and ep == 0:
+                assert abs(l - rt[0]) <= 1e-3 * abs(rt[0]) and abs(el - rh[0]) <= 1e-3 * abs(rh[0]), (seed, l, rt[0], el, rh[0])
+                assert np.allclose([p, r, f, a], rt[1:], atol=0.3) and np.allclose([ep_, er, ef, ea], rh[1:], atol=0.8), (seed, (p, r, f, a), rt, (ep_, er, ef, ea), rh)
+        fin_tr.append(f)
+        fin_he.append(ef)
+        print("traj %-4s seed %d  final train F %6.2f (ref %6.2f) | held-out F %6.2f (ref %6.2f) Acc %6.2f (ref %6.2f)   held-out F by epoch: %s | ref: %s" % (
+            dtype, seed, f, z["train"][si][-1][3], ef, z["held"][si][-1][3], ea, z["held"][si][-1][4],
+            " ".join("%.1f" % x for x in hist), " ".join("%.1f" % x for x in z["held"][si][:, 3])))
+    ref_he, ref_tr = z["held"][:, -1, 3], z["train"][:, -1, 3]
+    print("traj %-4s MEAN over %d seeds: final held-out F1 %.2f (reference %.2f, seed std %.2f) | final train F1 %.2f (reference %.2f)" % (
+        dtype, len(fin_he), np.mean(fin_he), ref_he.mean(), ref_he.std(ddof=1), np.mean(fin_tr), ref_tr.mean()))
+    assert abs(np.mean(fin_he) - ref_he.mean()) <= 1.5, (dtype, np.mean(fin_he), ref_he.mean())
+    assert abs(np.mean(fin_tr) - ref_tr.mean()) <= 1.5, (dtype, np.mean(fin_tr), ref_tr.mean())
+
+
 def test_coverage_sampler_matches_reference():
     """--coverage: same rows in the same order as the reference's pandas-based stratified sampler
     (digests produced by tests/golden/make_golden.py from /root/reference/utils/dataset/tod_asr_util.py)."""
