@@ -112,18 +112,26 @@ def cpu_baseline(labels, seconds_budget=25.0):
     torch.manual_seed(999)
     om = OracleModel(ocfg, labels.top2bottom, labels.n_bottom, 0.3)
     om.train()
-    b = synth.nbest_batch(cfg, labels, 8, 128, n_best=5, seed=999)
+    b = synth.nbest_batch(cfg, labels, 8, 128, n_best=5, seed=999, trans_len=32)
     t = {k: torch.from_numpy(v) for k, v in b.items()}
     opt = OracleBertAdam(list(om.named_parameters()), lr=3e-5, bert_lr=3e-5, warmup=0.1, t_total=1000)
     b2t = stc.bottom2top_matrix(labels.top2bottom)
-    oracle_step(om, opt, t, labels.top2bottom, b2t, skip_unused_transcript=True)      # warm-up
-    n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < seconds_budget * 0.5 and n < 12):
-        oracle_step(om, opt, t, labels.top2bottom, b2t, skip_unused_transcript=True)
-        n += 1
-    dt = time.time() - t0
-    return dict(value=round(8 * n / dt, 3), unit="utterances/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d steps of bert-base fp32 B=8 S=128 n_best=5 (fwd+loss+bwd+BertAdam), oracle on CPU" % n)
+    # What the reference's loop does per step (n_best_asr_bert.py:250-255 -> models/model.py:51-58): BOTH encoder passes - the
+    # transcript pass runs and is discarded unless --add_l2_loss (quirk Q4).  `value` times exactly that; the variant that skips
+    # the unused pass (what this build's GPU path does) is reported next to it.
+    def rate(skip, budget):
+        oracle_step(om, opt, t, labels.top2bottom, b2t, skip_unused_transcript=skip)      # warm-up
+        n, t0 = 0, time.time()
+        while n < 3 or (time.time() - t0 < budget and n < 12):
+            oracle_step(om, opt, t, labels.top2bottom, b2t, skip_unused_transcript=skip)
+            n += 1
+        return 8 * n / (time.time() - t0), n
+    full, n_full = rate(False, seconds_budget * 0.45)
+    lean, n_lean = rate(True, seconds_budget * 0.3)
+    return dict(value=round(full, 3), unit="utterances/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d steps of bert-base fp32 B=8 S=128 S_t=32 n_best=5 (ASR pass + the transcript pass the reference always runs, "
+                       "losses, backward, BertAdam), oracle on CPU" % n_full,
+                without_unused_transcript_pass=round(lean, 3), sample_without="%d steps" % n_lean)
 
 
 def time_wgrad_in_step(model, step, B, S, n_steps=3, operand_bytes=2.0):

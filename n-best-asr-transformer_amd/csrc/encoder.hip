@@ -22,6 +22,9 @@ int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, cons
                                   void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, Fp8Grad f8);
 int nbest_internal_amax_bf16(const void* x, int64_t n, uint32_t* out, hipStream_t st);
+void nbest_internal_rowred_batch_begin();
+void nbest_internal_rowred_batch_abort();
+int nbest_internal_rowred_batch_flush(hipStream_t st);
 int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void* ctx, void* ctx8, float* lse, int B, int S, int heads,
                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream);
 
@@ -112,7 +115,7 @@ static WsLayout ws_layout(const nbest_encoder_desc* d) {
     const size_t gb = al((size_t)((M + 127) / 128) * 2 * d->F * sizeof(float));   // fused column sums of the dU GEMM
     if (gb > w.red_bytes) w.red_bytes = gb;
   }
-  w.red = o; o += w.red_bytes;
+  w.red = o; o += 4 * w.red_bytes;      // four regions: the partial rows of a layer's four producers live until its one finalize
   w.slab_bytes = al(max_splitk_bytes(d, M));
   w.slab = o; o += w.slab_bytes;
   w.emb_bytes = al(nbest_embed_bwd_ws_bytes(M, d->H));
@@ -285,6 +288,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   void* dRd = hdrop ? (void*)(W + w.dRd) : dR;
   void* dB1 = W + w.dB1; void* dctx = W + w.dctx; void* dBig = W + w.dBig; void* dqkv = W + w.dqkv;
   void* red = W + w.red; void* slab = W + w.slab;
+  void* red1 = W + w.red + w.red_bytes; void* red2 = W + w.red + 2 * w.red_bytes; void* red3 = W + w.red + 3 * w.red_bytes;
   const uint32_t sb = d->drop_stream_base;
   // optional in-step timing of the weight-gradient GEMMs (see nbest_encoder_desc::wgrad_events)
   int ev_i = 4 * (d->L - layer_end);
@@ -311,10 +315,11 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N; g.ldu = N; g.ldc8 = N;
     g.epilogue = epi; g.out_scale = 1.f; g.out_scale_dev = d->w8_inv_scale + mat; g.a_amax = d->gamax_prev + a_idx;
     if (c_idx >= 0) { g.c8_amax_prev = d->gamax_prev + c_idx; g.c8_amax_new = d->gamax_new + c_idx; }
-    g.colsum_out = colsum; g.colsum_accumulate = accumulate; g.ws = red; g.ws_bytes = w.red_bytes;
+    g.colsum_out = colsum; g.colsum_accumulate = accumulate; g.ws = red1; g.ws_bytes = w.red_bytes;
     return nbest_gemm_fp8(&g, stream);
   };
 
+  struct BatchGuard { ~BatchGuard() { nbest_internal_rowred_batch_abort(); } } batch_guard;   // an error return mid-layer must not leave it open
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const nbest_layer_offsets& o = d->layers_host[l];
     char* Lb = A + a.layer0 + (size_t)l * a.layer_stride;
@@ -322,18 +327,19 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     void* r1 = Lb + a.o_r1; float* st1 = (float*)(Lb + a.o_st1); void* x1 = Lb + a.o_x1;
     void* u = Lb + a.o_u; void* hact = Lb + a.o_hact; void* r2 = Lb + a.o_r2; float* st2 = (float*)(Lb + a.o_st2);
     const uint32_t s0 = sb + 1 + 4 * l;
+    nbest_internal_rowred_batch_begin();    // the layer's four bias / LayerNorm-parameter reductions: one finalize launch at its end
     const uint8_t* x8 = (const uint8_t*)(Lb + a.o_x8); const uint8_t* ctx8 = (const uint8_t*)(Lb + a.o_ctx8);
     const uint8_t* x18 = (const uint8_t*)(Lb + a.o_x18); const uint8_t* h8 = (const uint8_t*)(Lb + a.o_h8);
     // LN2 backward: dR (residual branch), dRd (dense branch, under the dropout mask), db2
     // (with fp8 dgrads / wgrads the bf16 forms of dRd, dBig and dqkv have no reader: only their e4m3 copies are written)
     RUN(nbest_internal_layernorm_bwd8(dA, r2, st2, P.P(o.ln2_g), dR, (hdrop && !f8b) ? dRd : nullptr, G(o.ln2_g), G(o.ln2_b), G(o.b2), M, H, dt,
-                                      accumulate, d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream, fg(dRd8, 4 * l + 0)));
+                                      accumulate, d->hidden_drop, d->seed, s0 + 2, red, w.red_bytes, stream, fg(dRd8, 4 * l + 0)));   // partial rows: region 0
     // FFN-down: dgrad fused with GELU' -> dU ; wgrad
     // (the FFN-up bias gradient = column sums of dU is fused into this epilogue)
     if (f8b) {
       RUN(dgrad8(dRd8, 4 * l + 0, o.w2, 4 * l + 3, nullptr, F, H, NBEST_EPI_DGELU, nullptr, u, dBig8, 4 * l + 1, G(o.b1)));
     } else {
-      RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red, w.red_bytes, accumulate,
+      RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red1, w.red_bytes, accumulate,
                0.f, 0, 0, st, G(o.b1)));
       if (rec) RUN(nbest_internal_amax_bf16(dBig, M * F, d->gamax_new + 4 * l + 1, st));   // calibration pass: this producer is a bf16 kernel
     }
@@ -352,7 +358,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     stamp(1);
     // LN1 backward
     RUN(nbest_internal_layernorm_bwd8(dB1, r1, st1, P.P(o.ln1_g), dR, (hdrop && !f8b) ? dRd : nullptr, G(o.ln1_g), G(o.ln1_b), G(o.bo), M, H, dt,
-                                      accumulate, d->hidden_drop, d->seed, s0 + 1, red, w.red_bytes, stream, fg(dRd8, 4 * l + 2)));
+                                      accumulate, d->hidden_drop, d->seed, s0 + 1, red2, w.red_bytes, stream, fg(dRd8, 4 * l + 2)));
     // attention output projection: dgrad ; wgrad
     if (f8b) RUN(dgrad8(dRd8, 4 * l + 2, o.wo, 4 * l + 1, dctx, H, H, NBEST_EPI_NONE, nullptr, nullptr, nullptr, -1, nullptr));
     else RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
@@ -362,7 +368,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
                   accumulate, 0.f, 0, 0, st));
     stamp(1);
     // attention backward -> dqkv ; QKV bias gradient
-    RUN(nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, f8b ? nullptr : dqkv, G(o.bqkv), accumulate, red, w.red_bytes, d->B, d->S, d->heads, 64,
+    RUN(nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, f8b ? nullptr : dqkv, G(o.bqkv), accumulate, red3, w.red_bytes, d->B, d->S, d->heads, 64,
                                       dt, d->attn_drop, d->seed, s0 + 0, stream, fg(dqkv8, 4 * l + 3)));
     // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
     if (f8b) RUN(dgrad8(dqkv8, 4 * l + 3, o.wqkv, 4 * l + 0, dA, H, 3 * H, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
@@ -372,6 +378,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     else RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
                   w.slab_bytes, accumulate, 0.f, 0, 0, st));
     stamp(1);
+    RUN(nbest_internal_rowred_batch_flush(st));
   }
   if (!with_embeddings) return NBEST_OK;
   if (!accumulate) {

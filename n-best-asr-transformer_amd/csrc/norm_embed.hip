@@ -646,18 +646,83 @@ static int check_h(int H) {
   return NBEST_OK;
 }
 
+// ---- deferred finalizes ----------------------------------------------------------------------------------------------
+// A backward layer has four producers of partial rows (LayerNorm-backward x 2, the fused column sums of the dU GEMM, the
+// attention backward's bias gradient); finalised one by one that is four 5-us launches of pure latency per layer (49 per
+// step).  nbest_encoder_backward opens a batch per layer: while it is open finalize() only RECORDS its job (the producers
+// write their partial rows into regions of their own) and one launch at the end of the layer sums them all.
+constexpr int kMaxBatch = 8;
+struct RowredJob {
+  const float* part;
+  int nblk, N, nout;
+  RowredOut o;
+};
+struct RowredJobs {
+  RowredJob j[kMaxBatch];
+};
+thread_local RowredJobs* t_batch = nullptr;
+thread_local int t_batch_n = 0;
+
+__global__ __launch_bounds__(1024) void rowred_finalize_multi_kernel(RowredJobs jobs) {
+  __shared__ float sm[32][33];
+  const RowredJob& jb = jobs.j[blockIdx.z];
+  const int k = blockIdx.y, N = jb.N, nblk = jb.nblk;
+  if (k >= jb.nout || (int)blockIdx.x * 32 >= N) return;        // block-uniform
+  float* outp = jb.o.out[k];
+  const int col = blockIdx.x * 32 + threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < N && outp != nullptr) {
+    const float* p = jb.part + (int64_t)k * nblk * N + col;
+    int b = threadIdx.y;
+    for (; b + 96 < nblk; b += 128) {
+      s0 += p[(int64_t)b * N]; s1 += p[(int64_t)(b + 32) * N]; s2 += p[(int64_t)(b + 64) * N]; s3 += p[(int64_t)(b + 96) * N];
+    }
+    for (; b < nblk; b += 32) s0 += p[(int64_t)b * N];
+  }
+  sm[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.y == 0 && col < N && outp != nullptr) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += sm[r][threadIdx.x];
+    outp[col] = jb.o.accumulate[k] ? outp[col] + s : s;
+  }
+}
+
 static int finalize(const float* part, int nblk, int N, float* o0, int a0, float* o1, int a1, float* o2, int a2,
                     hipStream_t st) {
   RowredOut o;
   o.out[0] = o0; o.out[1] = o1; o.out[2] = o2;
   o.accumulate[0] = a0; o.accumulate[1] = a1; o.accumulate[2] = a2;
   const int nout = o2 ? 3 : (o1 ? 2 : 1);
+  if (t_batch != nullptr && t_batch_n < kMaxBatch) {              // deferred: summed by nbest_internal_rowred_batch_flush
+    RowredJob& jb = t_batch->j[t_batch_n++];
+    jb.part = part; jb.nblk = nblk; jb.N = N; jb.nout = nout; jb.o = o;
+    return NBEST_OK;
+  }
   rowred_finalize_kernel<<<dim3((N + 31) / 32, nout), dim3(32, 32), 0, st>>>(part, nblk, N, o);
   NB_LAUNCH_CHECK();
   return NBEST_OK;
 }
 
 }  // namespace
+
+// Deferred finalizes (see RowredJobs): between begin and flush every finalize of THIS thread is recorded instead of launched; the
+// caller guarantees that the recorded producers wrote their partial rows to distinct memory.  flush launches one kernel for all.
+static thread_local RowredJobs t_jobs_storage;
+void nbest_internal_rowred_batch_begin() { t_batch = &t_jobs_storage; t_batch_n = 0; }
+void nbest_internal_rowred_batch_abort() { t_batch = nullptr; t_batch_n = 0; }     // error paths: never leave a batch open
+int nbest_internal_rowred_batch_flush(hipStream_t st) {
+  RowredJobs* b = t_batch;
+  const int n = t_batch_n;
+  t_batch = nullptr; t_batch_n = 0;
+  if (b == nullptr || n == 0) return NBEST_OK;
+  int maxN = 0, maxout = 1;
+  for (int i = 0; i < n; ++i) { if (b->j[i].N > maxN) maxN = b->j[i].N; if (b->j[i].nout > maxout) maxout = b->j[i].nout; }
+  rowred_finalize_multi_kernel<<<dim3((maxN + 31) / 32, maxout, n), dim3(32, 32), 0, st>>>(*b);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
 
 // out[n] (+)= sum over `nrows` partial rows (used by the fused bias-gradient epilogues of the GEMM / attention)
 int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st) {

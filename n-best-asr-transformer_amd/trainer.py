@@ -99,6 +99,8 @@ class GradReducer:
         self.sparse = (ws.numel * 4 > (256 << 20)) if sparse_word_grad is None else bool(sparse_word_grad)
         self._tok = None          # (unique row ids of this rank's shard, async count exchange) of the running step
         self._sparse = None
+        self._side = None         # side stream + pinned buffer that bring the per-rank row counts to the host
+        self._cnt_host = None
 
     # ---- sparse word-embedding rows ------------------------------------------------------------------------------------
     def set_step_tokens(self, *id_tensors, rows=None):
@@ -115,12 +117,31 @@ class GradReducer:
         n = torch.tensor([rows.numel()], dtype=torch.long, device=dev)
         counts = torch.zeros(self.world, dtype=torch.long, device=dev)
         work = _all_gather_flat(counts, n)
-        self._tok = (rows, counts, work)
+        # The host needs the counts (they size the row exchange) - but must not wait for the COMPUTE stream to get them: that
+        # would drain the whole backward before the row all-gathers, the optimizer and the next step are enqueued (round 2 did a
+        # counts.tolist() there).  So the counts go to pinned host memory on a side stream, behind the collective only, with an
+        # event; by the time the embedding backward has been enqueued that event completed long ago.
+        ev = None
+        if dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+                self._cnt_host = torch.empty(self.world, dtype=torch.long).pin_memory()
+            with torch.cuda.stream(self._side):
+                work.wait()                                   # orders the side stream behind the collective, not the host
+                self._cnt_host.copy_(counts, non_blocking=True)
+                counts.record_stream(self._side)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+        self._tok = (rows, counts, work, ev)
 
     def _start_sparse(self):
-        rows, counts, work = self._tok
-        work.wait()
-        cnt = counts.tolist()
+        rows, counts, work, ev = self._tok
+        if ev is not None:
+            ev.synchronize()                                  # the side-stream copy only; the compute stream keeps running
+            cnt = self._cnt_host.tolist()
+        else:                                                 # CPU tensors (gloo tests): the collective completes on the host
+            work.wait()
+            cnt = counts.tolist()
         cap = max(max(cnt), 1)
         lo, hi, shape = self.word
         G = self.arena.g[lo:hi].view(shape)
@@ -489,7 +510,10 @@ def eval_epoch(model, data, opt, memory, fp=None, efp=None):
     onto = getattr(opt, "ontology", None)
     counts, losses, chunks = (0, 0, 0, 0, 0), [], []
     split = encoded(data, opt, memory)
-    lists = batch_indices(len(split), opt.batchSize)
+    # the reference builds its valid / test loaders with int(batchSize / n_accum_steps) too (n_best_asr_bert.py:529-531), and the
+    # record is the mean over batches of sum / batch size: the partition (and the weight of a short last batch) must be the same
+    n_accum = max(1, int(getattr(opt, "n_accum_steps", 1) or 1))
+    lists = batch_indices(len(split), max(1, int(opt.batchSize / n_accum)))
     for bi, mine, b in Prefetcher(split, lists, model.device, rank, world):
         if not mine:
             continue

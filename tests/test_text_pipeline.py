@@ -78,6 +78,27 @@ def test_train_and_eval_epoch_match_reference(labels):
 
 
 @pytest.mark.gpu
+def test_eval_partition_follows_accumulation_like_the_reference(labels):
+    """With gradient accumulation (--n_layers 12 -> n_accum_steps = 4) the reference builds its valid / test loaders with
+    int(batchSize / n_accum_steps) as well (n_best_asr_bert.py:529-531); the reported loss is the mean over batches of sum / batch
+    size, so the partition matters: eval_epoch(batchSize 8, n_accum_steps 4) must equal eval_epoch(batchSize 2)."""
+    from nbest_amd.model import NBestSTCModel
+    z, vocab, data = _load()
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=len(vocab), hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.float32, dropout=0.0)
+    m.load_reference_state(synth.model_state(cfg, labels, seed=int(z["seed"])))
+    memory = dict(label2idx=json.loads(str(z["label2idx"])), idx2label=labels.idx2label)
+    mk = lambda bs, na: types.SimpleNamespace(batchSize=bs, n_accum_steps=na, tokenizer=inputs.WordPieceTokenizer(vocab), pre_trained_model="bert",
+                                               tod_pre_trained_model=None, without_system_act=False, add_l2_loss=True, add_segment_ids=True)
+    d = tuple(list(x[:23]) for x in data)          # 23 utterances: a short last batch in both partitions
+    a = trainer.eval_epoch(m, d, mk(8, 4), memory)
+    b = trainer.eval_epoch(m, d, mk(2, 1), memory)
+    c = trainer.eval_epoch(m, d, mk(8, 1), memory)
+    assert a[0] == pytest.approx(b[0], rel=1e-6) and a[1] == b[1] and a[2] == b[2]
+    assert abs(a[0] - c[0]) > 1e-6 * abs(a[0])      # ... and the partition does change the record (short last batch)
+
+
+@pytest.mark.gpu
 def test_utterance_longer_than_256_tokens_runs_untruncated(labels):
     """The reference never truncates (utils/bert_xlnet_inputs.py:87-94; --max_seq_len is ignored there): an utterance whose
     n-best list tokenises to more than 256 positions must train and evaluate in the default bf16 path without
