@@ -183,6 +183,20 @@ int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, const void* ct
                         int B, int S, int heads, int d, int dtype, float drop_p, uint64_t seed,
                         uint32_t drop_stream, nbest_stream_t stream);
 
+/* The same pair with the dropout decisions handed from the forward to the backward (bf16, S <= 256): the forward writes its
+ * keep decisions as bit words keep[B * heads][ceil(S/32)][32 ceil(S/32)] (bit j of word (key block kb, query q) = key 32 kb + j
+ * kept; nbest_attention_keep_bytes() bytes, 0 when the shape has no such path), the backward reads them instead of hashing
+ * every score element again.  Same decisions, hence the same results as the plain pair up to fma contraction in the last bit;
+ * keep may be NULL (then identical to the plain pair). */
+size_t nbest_attention_keep_bytes(int B, int S, int heads);
+int nbest_attention_fwd_keep(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S,
+                             int heads, int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream,
+                             void* keep, nbest_stream_t stream);
+int nbest_attention_bwd_keep(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx,
+                             const float* lse, void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                             int B, int S, int heads, int d, int dtype, float drop_p, uint64_t seed,
+                             uint32_t drop_stream, const void* keep, nbest_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K5  LayerNorm over the hidden dimension (BertSelfOutput / BertOutput LayerNorm,
  * installed modeling_bert.py:282-293, 340-351).  stats[m] = {mean, rstd} fp32.                      */

@@ -225,7 +225,10 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
 template <int NKB>
 __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                             bf16* __restrict__ ctx, float* __restrict__ lse, int S, int heads,
-                                                            int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8) {
+                                                            int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8,
+                                                            uint32_t* __restrict__ keep_out) {
+  // keep_out (optional, with dropout): the keep decisions as bit words [bh][key block][query] (bit j = key 32 kb + j kept), so
+  // that the backward pass reads one word per (query, key block) instead of hashing every score element again
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int Sp = NKB * 32;
   constexpr bool kOne = (NKB <= 4);           // one query block per wave
@@ -312,27 +315,44 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(
       const uint32_t hb = ((rowbase >> 1) + 2u * (uint32_t)hh) * 0x9E3779B9U + drop.key;
       const float ids = inv * drop.scale;
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+      for (int kb = 0; kb < NKB; ++kb) {
+        uint32_t kw = 0;          // this lane's 16 keys of the block, at the bit positions of lane half 0 (crow(r, 0)); shifted by 4 hh below
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const uint32_t hsh = nb_hash32(hb + (uint32_t)((32 * kb + crow(r, 0)) >> 1) * 0x9E3779B9U);
-          const float p0 = ((hsh & 0xFFFFu) >= drop.thr16) ? sc[kb][r] * ids : 0.f;
-          const float p1 = ((hsh >> 16) >= drop.thr16) ? sc[kb][r + 1] * ids : 0.f;
+          const bool k0 = (hsh & 0xFFFFu) >= drop.thr16, k1 = (hsh >> 16) >= drop.thr16;
+          const float p0 = k0 ? sc[kb][r] * ids : 0.f;
+          const float p1 = k1 ? sc[kb][r + 1] * ids : 0.f;
+          kw |= (k0 ? (1u << crow(r, 0)) : 0u) | (k1 ? (2u << crow(r, 0)) : 0u);
           pa[kb][r >> 3][r & 7] = (bf16)p0;
           pa[kb][r >> 3][(r & 7) + 1] = (bf16)p1;
         }
+        if (keep_out) {
+          kw <<= 4 * hh;
+          kw |= (uint32_t)__shfl_xor((int)kw, 32, 64);
+          if (hh == 0 && qrow < Sp) keep_out[((int64_t)bh * NKB + kb) * Sp + qrow] = kw;
+        }
+      }
     } else {
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+      for (int kb = 0; kb < NKB; ++kb) {
+        uint32_t kw = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float pv = sc[kb][r] * inv;
           if (drop.thr16) {
             const int key = 32 * kb + crow(r, hh);
-            pv = nb_keep(drop, (uint32_t)((bh * S + qrow) * S + key)) ? pv * drop.scale : 0.f;
+            const bool kp = nb_keep(drop, (uint32_t)((bh * S + qrow) * S + key));
+            pv = kp ? pv * drop.scale : 0.f;
+            kw |= kp ? (1u << crow(r, hh)) : 0u;
           }
           pa[kb][r >> 3][r & 7] = (bf16)pv;
         }
+        if (keep_out && drop.thr16) {
+          kw |= (uint32_t)__shfl_xor((int)kw, 32, 64);
+          if (hh == 0 && qrow < Sp) keep_out[((int64_t)bh * NKB + kb) * Sp + qrow] = kw;
+        }
+      }
     }
     f32x16 o0, o1;
 #pragma unroll
@@ -509,27 +529,33 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16* __restri
 #endif  // NBEST_EXPERIMENTS
 
 // ---- backward, second structure: S <= 256, small LDS footprint -----------------------------------------
-// One wave per 32-key block (4 waves for S <= 128, 8 for S <= 256).  LDS: Qt | Kt | dOt ([Sp][64] bf16) and a
-// DOUBLE-BUFFERED dS slab of ONE query block ([32 q][Sp keys]); V fragments come straight from HBM into
-// registers (row fragments are 16 contiguous bytes per lane).  After the barrier that completes the slab of
-// query block qb, wave (qb mod NW) turns it into dQ[qb] = dS . K while everybody proceeds with qb+1.
-// 65 KiB at S = 128 -> two workgroups per CU; 130 KiB at S = 256.
-template <int NKB>
+// One wave per 32-key block (4 waves for S <= 128, 8 for S <= 256).  LDS: Qt | Kt | dOt ([Sp][64] bf16), the dS image of TWO query
+// blocks and small per-row arrays; V fragments come straight from HBM into registers (row fragments are 16 contiguous bytes per
+// lane).  After the barrier that completes the dS image of query block qb, wave (qb mod NW) turns it into dQ[qb] = dS . K while
+// everybody proceeds with qb+1.  67 KiB at S = 128 -> two workgroups per CU; 136 KiB at S = 256.
+// Round 3 (the kernel ran at 47 vector instructions per score element, two thirds of them bookkeeping):
+//   * dS crosses LDS TRANSPOSED: a lane (= key) holds four consecutive queries per register quad, so it stores them as one 8-byte
+//     row piece of a [key][64 q] image (the two 32-query halves of a 128-byte row double-buffer even / odd query blocks) instead of
+//     sixteen 2-byte scatters into a [q][key] slab; the dQ product reads the image with the hardware-transposed reads it already
+//     uses for K (same swizzle, same helper);
+//   * KB: the dropout decisions come from the forward's keep words ([bh][key block][query], one bit per key; 2 KiB per head in
+//     LDS): one AND per element instead of a three-multiply hash;
+//   * exponent in units of log2 (lse pre-multiplied in the prologue): subtract, fma, v_exp.
+template <int NKB, bool KB>
 __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_kernel(
     const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask, const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
     const float* __restrict__ lse, bf16* __restrict__ dqkv, float* __restrict__ colpart, int S, int heads, int H, float scale,
-    DropCfg drop, Fp8Grad f8) {
+    DropCfg drop, Fp8Grad f8, const uint32_t* __restrict__ keep) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int Sp = NKB * 32;
   constexpr int NW = (NKB <= 4) ? 4 : 8, NT = NW * 64;
-  constexpr int RS = (Sp <= 128) ? 256 : 512;         // dS slab row stride in bytes: a power of two (the XOR swizzle
-                                                       // permutes 16 chunks inside an aligned 256-byte group)
   char* Qt = lds;
   char* Kt = Qt + Sp * 128;
   char* dOt = Kt + Sp * 128;
-  char* dSb = dOt + Sp * 128;                          // [2][32][RS]
-  float* lse_s = (float*)(dSb + 2 * 32 * RS);
+  char* dST = dOt + Sp * 128;                          // [Sp keys][64 q] bf16, chunk ^= gsw(key) like every [rows][64] tile
+  float* lse_s = (float*)(dST + Sp * 128);             // lse * log2(e)
   float* del_s = lse_s + Sp;
+  uint32_t* kw_s = (uint32_t*)(del_s + Sp);            // KB: [NKB key blocks][Sp queries] keep words of this head
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
   const int ld = 3 * H;
@@ -541,7 +567,10 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
   stage_rows(rs, Qt, Sp, h * 64, ld, tid, NT);
   stage_rows(rs, Kt, Sp, H + h * 64, ld, tid, NT);
   stage_rows(rsd, dOt, Sp, h * 64, H, tid, NT);
-  for (int k = tid; k < Sp; k += NT) lse_s[k] = (k < S) ? lse[(int64_t)bh * S + k] : INFINITY;
+  for (int k = tid; k < Sp; k += NT) lse_s[k] = (k < S) ? lse[(int64_t)bh * S + k] * 1.4426950408889634f : INFINITY;
+  if (KB) {
+    for (int i = tid; i < NKB * Sp; i += NT) kw_s[i] = keep[(int64_t)bh * NKB * Sp + i];
+  }
   {  // delta[q] = sum_d dO[q][d] * O[q][d]; two threads per row
     const int r = tid >> 1, half = tid & 1;
     float sdel = 0.f;
@@ -564,6 +593,8 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
   const int key = 32 * wave + (lane & 31);
   const bool kvalid = (wave < NKB) && key < S;
   const float mk = (kvalid && mask[b * S + key]) ? 0.f : -INFINITY;
+  const uint32_t lanebit = 1u << (lane & 31);
+  const float sl2 = scale * 1.4426950408889634f;
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -579,10 +610,12 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
   f32x16 dk0, dk1, dv0, dv1, dq0, dq1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dk0[r] = dk1[r] = dv0[r] = dv1[r] = dq0[r] = dq1[r] = 0.f;
+  char* dsrow = dST + key * 128;                       // this lane's row of the dS image
+  const int dsg = gsw(key);
 
 #pragma unroll 1
   for (int qb = 0; qb < NKB; ++qb) {
-    char* slab = dSb + (qb & 1) * 32 * RS;
+    const int half = qb & 1;
     if (wave < NKB) {
       f32x16 sa, da;
 #pragma unroll
@@ -594,25 +627,33 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
       }
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const f32x4 l4 = *(const f32x4*)(lse_s + 32 * qb + 8 * r4 + 4 * hh);
-        const f32x4 d4 = *(const f32x4*)(del_s + 32 * qb + 8 * r4 + 4 * hh);
+        const int qoff = 32 * qb + 8 * r4 + 4 * hh;      // first of this lane's four consecutive queries
+        const f32x4 l4 = *(const f32x4*)(lse_s + qoff);
+        const f32x4 d4 = *(const f32x4*)(del_s + qoff);
+        i32x4 k4 = {0, 0, 0, 0};
+        if (KB) k4 = *(const i32x4*)(kw_s + wave * Sp + qoff);
+        bf16x4 pk;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * r4 + e;
-          const int ql = 8 * r4 + 4 * hh + e;           // query row inside the block
-          const int q = 32 * qb + ql;
-          const float pv = __expf(sa[r] * scale + mk - l4[e]);
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, mk - l4[e]));
           float pt = pv, dp = da[r];
-          if (drop.thr16) {
-            const bool keep = nb_keep(drop, (uint32_t)((bh * S + q) * S + key));
-            pt = keep ? pv * drop.scale : 0.f;
-            dp = keep ? dp * drop.scale : 0.f;
+          if (KB) {
+            const float kf_ = ((uint32_t)k4[e] & lanebit) ? drop.scale : 0.f;
+            pt = pv * kf_;
+            dp = dp * kf_;
+          } else if (drop.thr16) {
+            const bool keep_ = nb_keep(drop, (uint32_t)((bh * S + qoff + e) * S + key));
+            pt = keep_ ? pv * drop.scale : 0.f;
+            dp = keep_ ? dp * drop.scale : 0.f;
           }
           const float ds = pv * (dp - d4[e]) * scale;
           sa[r] = pt;
           da[r] = ds;
-          *(bf16*)(slab + ql * RS + ((((key >> 3) ^ (ql & 15))) << 4) + (key & 7) * 2) = (bf16)ds;
+          pk[e] = (bf16)ds;
         }
+        const int col = 32 * half + 8 * r4 + 4 * hh;
+        *(bf16x4*)(dsrow + (((col >> 3) ^ dsg) << 4) + ((col & 4) ? 8 : 0)) = pk;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -623,21 +664,19 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsa, tr_frag<true>(Qt, 32 * qb + 16 * s2, 32, lane), dk1, 0, 0, 0);
       }
     }
-    __syncthreads();   // the dS slab of query block qb is complete (and slab (qb+1)&1 is free again)
+    __syncthreads();   // the dS image half of query block qb is complete (and the other half is free again)
     if (wave == (qb % NW)) {
 #pragma unroll
       for (int ks = 0; ks < 2 * NKB; ++ks) {
-        const int row = lane & 31;
-        const int c = 2 * ks + hh;
-        const bf16x8 dsf = *(const bf16x8*)(slab + row * RS + ((c ^ (row & 15)) << 4));
+        const bf16x8 dsf = tr_frag<false>(dST, 16 * ks, 32 * half, lane);       // dS[q = lane & 31][16 keys of step ks]
         dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 0, lane), dq0, 0, 0, 0);
         dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dsf, tr_frag<false>(Kt, 16 * ks, 32, lane), dq1, 0, 0, 0);
       }
     }
   }
-  __syncthreads();  // everyone is done with Qt / Kt / dOt / slabs: reuse them as output images
+  __syncthreads();  // everyone is done with Qt / Kt / dOt / the dS image: reuse them as output images
   if (colpart) {
-    float* cs = (float*)dSb;   // [NW][3][64]
+    float* cs = (float*)dST;   // [NW][3][64]
     const f32x16* tiles[6] = {&dq0, &dq1, &dk0, &dk1, &dv0, &dv1};
 #pragma unroll
     for (int t6 = 0; t6 < 6; ++t6) {
@@ -999,15 +1038,21 @@ __global__ __launch_bounds__(512) void attn_bwd_long_bf16_kernel(const bf16* __r
 }
 
 static size_t bwd2_lds_bytes(int nkb) {
-  const int Sp = nkb * 32, rs = (Sp <= 128) ? 256 : 512;
-  return (size_t)Sp * 128 * 3 + (size_t)2 * 32 * rs + (size_t)Sp * 8;
+  const int Sp = nkb * 32;       // Q | K | dO | dS image ([Sp][64] bf16 each), lse, delta, keep words [nkb][Sp]
+  return (size_t)Sp * 128 * 4 + (size_t)Sp * 8 + (size_t)nkb * Sp * 4;
 }
 template <int NKB>
 static void launch_bwd2(const bf16* qkv, const uint8_t* mask, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv,
-                        float* colpart, int B, int S, int heads, int H, float scale, DropCfg d, hipStream_t st, Fp8Grad f8) {
+                        float* colpart, int B, int S, int heads, int H, float scale, DropCfg d, hipStream_t st, Fp8Grad f8,
+                        const uint32_t* keep) {
   const size_t sm = bwd2_lds_bytes(NKB);
-  (void)hipFuncSetAttribute((const void*)attn_bwd2_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  attn_bwd2_bf16_kernel<NKB><<<B * heads, (NKB <= 4 ? 4 : 8) * 64, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d, f8);
+  if (keep && d.thr16) {      // dropout decisions from the forward's keep words
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_bf16_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    attn_bwd2_bf16_kernel<NKB, true><<<B * heads, (NKB <= 4 ? 4 : 8) * 64, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d, f8, keep);
+  } else {                    // no dropout, or no keep words (stand-alone calls): the decisions are hashed again
+    (void)hipFuncSetAttribute((const void*)attn_bwd2_bf16_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    attn_bwd2_bf16_kernel<NKB, false><<<B * heads, (NKB <= 4 ? 4 : 8) * 64, sm, st>>>(qkv, mask, ctx, dctx, lse, dqkv, colpart, S, heads, H, scale, d, f8, nullptr);
+  }
 }
 
 // K | V | key-mask addends (| 4 output images; S <= 128 restages the output over the K rows, which are dead by then)
@@ -1021,10 +1066,10 @@ static size_t bwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * (4 * 128 + 256)
 
 template <int NKB>
 static void launch_fwd(const bf16* qkv, const uint8_t* mask, bf16* ctx, float* lse, int B, int S, int heads, int H, float scale,
-                       DropCfg d, hipStream_t st, uint8_t* ctx8) {
+                       DropCfg d, hipStream_t st, uint8_t* ctx8, uint32_t* keep) {
   const size_t sm = fwd_lds_bytes(NKB);
   (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  attn_fwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8);
+  attn_fwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8, keep);
 }
 #ifdef NBEST_EXPERIMENTS
 template <int NKB>
@@ -1047,8 +1092,15 @@ static int check_common(const char* who, int B, int S, int heads, int d, int dty
 }  // namespace
 
 // ctx8 != NULL (bf16 only): also write the e4m3 copy of ctx that the fp8 attention-output GEMM reads
+// keep (bf16, S <= 256, optional): receives the dropout keep words [B * heads][ceil(S / 32)][32 ceil(S / 32)] for the backward pass
+// (nbest_internal_attention_keep_bytes)
+size_t nbest_internal_attention_keep_bytes(int B, int S, int heads) {
+  const size_t nkb = (size_t)(S + 31) / 32;
+  return (S <= 256) ? (size_t)B * heads * nkb * nkb * 32 * sizeof(uint32_t) : 0;
+}
 int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void* ctx, void* ctx8, float* lse, int B, int S, int heads,
-                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream,
+                                  uint32_t* keep) {
   NB_CHECK(qkv && key_mask && ctx && lse, NBEST_ERR_ARG, "attention_fwd: null pointer");
   if (int e = check_common("attention_fwd", B, S, heads, d, dtype)) return e;
   hipStream_t st = (hipStream_t)stream;
@@ -1069,7 +1121,7 @@ int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void
       NB_LAUNCH_CHECK();
       return NBEST_OK;
     }
-#define F(N) case N: launch_fwd<N>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, S, heads, H, scale, dc, st, (uint8_t*)ctx8); break;
+#define F(N) case N: launch_fwd<N>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, S, heads, H, scale, dc, st, (uint8_t*)ctx8, keep); break;
     switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
 #undef F
   }
@@ -1079,7 +1131,7 @@ int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void
 
 extern "C" int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
                                    int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
-  return nbest_internal_attention_fwd8(qkv, key_mask, ctx, nullptr, lse, B, S, heads, d, dtype, drop_p, seed, drop_stream, stream);
+  return nbest_internal_attention_fwd8(qkv, key_mask, ctx, nullptr, lse, B, S, heads, d, dtype, drop_p, seed, drop_stream, stream, nullptr);
 }
 
 int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
@@ -1093,7 +1145,8 @@ extern "C" size_t nbest_attention_bwd_ws_bytes(int B, int S, int heads) {
 // f8 (bf16 only): e4m3 copy (scaled by the previous pass's amax) + amax of dqkv for the fp8 QKV dgrad GEMM
 int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
                                   void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
-                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, Fp8Grad f8) {
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, Fp8Grad f8,
+                                  const uint32_t* keep) {
   NB_CHECK(qkv && key_mask && ctx && dctx && lse && (dqkv || (f8.out8 && dtype == NBEST_BF16)), NBEST_ERR_ARG, "attention_bwd: null pointer");
   if (int e = check_common("attention_bwd", B, S, heads, d, dtype)) return e;
   NB_CHECK(!dbias || (ws && ws_bytes >= nbest_attention_bwd_ws_bytes(B, S, heads)), NBEST_ERR_WORKSPACE,
@@ -1136,7 +1189,7 @@ int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, cons
     return NBEST_OK;
   }
 #endif
-#define F(N) case N: launch_bwd2<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st, f8); break;
+#define F(N) case N: launch_bwd2<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st, f8, keep); break;
   switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
 #undef F
   NB_LAUNCH_CHECK();
@@ -1148,5 +1201,22 @@ extern "C" int nbest_attention_bwd(const void* qkv, const uint8_t* key_mask, con
                                    void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
                                    int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
   return nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, dqkv, dbias, accumulate, ws, ws_bytes, B, S, heads, d, dtype, drop_p,
-                                       seed, drop_stream, stream, Fp8Grad{nullptr, nullptr, nullptr});
+                                       seed, drop_stream, stream, Fp8Grad{nullptr, nullptr, nullptr}, nullptr);
+}
+
+extern "C" size_t nbest_attention_keep_bytes(int B, int S, int heads) { return nbest_internal_attention_keep_bytes(B, S, heads); }
+extern "C" int nbest_attention_fwd_keep(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
+                                        int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, void* keep,
+                                        nbest_stream_t stream) {
+  const bool ok = keep && dtype == NBEST_BF16 && nbest_internal_attention_keep_bytes(B, S, heads) > 0;
+  return nbest_internal_attention_fwd8(qkv, key_mask, ctx, nullptr, lse, B, S, heads, d, dtype, drop_p, seed, drop_stream, stream,
+                                       ok ? (uint32_t*)keep : nullptr);
+}
+extern "C" int nbest_attention_bwd_keep(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
+                                        void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
+                                        int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, const void* keep,
+                                        nbest_stream_t stream) {
+  const bool ok = keep && dtype == NBEST_BF16 && nbest_internal_attention_keep_bytes(B, S, heads) > 0;
+  return nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, dqkv, dbias, accumulate, ws, ws_bytes, B, S, heads, d, dtype, drop_p,
+                                       seed, drop_stream, stream, Fp8Grad{nullptr, nullptr, nullptr}, ok ? (const uint32_t*)keep : nullptr);
 }

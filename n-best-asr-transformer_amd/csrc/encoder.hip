@@ -20,13 +20,15 @@ int nbest_internal_layernorm_bwd8(const void* dy, const void* x, const float* st
                                   size_t ws_bytes, nbest_stream_t stream, Fp8Grad f8);
 int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
                                   void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,
-                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, Fp8Grad f8);
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, Fp8Grad f8,
+                                  const uint32_t* keep);
+size_t nbest_internal_attention_keep_bytes(int B, int S, int heads);
 int nbest_internal_amax_bf16(const void* x, int64_t n, uint32_t* out, hipStream_t st);
 void nbest_internal_rowred_batch_begin();
 void nbest_internal_rowred_batch_abort();
 int nbest_internal_rowred_batch_flush(hipStream_t st);
 int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void* ctx, void* ctx8, float* lse, int B, int S, int heads,
-                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream);
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, uint32_t* keep);
 
 namespace {
 
@@ -36,6 +38,7 @@ struct ActLayout {
   size_t esz, X, emb_stats, layer0, layer_stride;
   size_t o_qkv, o_ctx, o_lse, o_r1, o_st1, o_x1, o_u, o_hact, o_r2, o_st2;
   size_t o_x8, o_ctx8, o_x18, o_h8;   // fp8 forward ("fp8w"): e4m3 copies of the four GEMM inputs of the layer, kept for the fp8 weight gradients
+  size_t o_keep, keep_bytes;          // bf16, S <= 256: attention-dropout keep words of the layer (forward -> backward)
   size_t total;
   int64_t M;
 };
@@ -61,6 +64,8 @@ static ActLayout act_layout(const nbest_encoder_desc* d) {
   a.o_hact = p; p += MF;
   a.o_r2 = p; p += MH;
   a.o_st2 = p; p += st;
+  a.keep_bytes = (d->dtype == NBEST_BF16) ? nbest_internal_attention_keep_bytes(d->B, d->S, d->heads) : 0;
+  a.o_keep = p; p += al(a.keep_bytes);
   a.o_x8 = a.o_ctx8 = a.o_x18 = a.o_h8 = 0;
   if (d->w8) {   // only the fp8 mode pays for them (+ (3 H + F) bytes per token and layer)
     const size_t MH8 = al((size_t)a.M * d->H), MF8 = al((size_t)a.M * d->F);
@@ -231,7 +236,8 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     } else
     RUN(gemm(dt, X(l), P.W(o.wqkv), qkv, M, 3 * H, H, H, H, 3 * H, 0, 0, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, 0, nullptr, 0,
              nullptr, 0, 0, 0.f, 0, 0, st));
-    RUN(nbest_internal_attention_fwd8(qkv, key_mask, ctx, ctx8, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream));
+    uint32_t* keepw = (a.keep_bytes && d->attn_drop > 0.f) ? (uint32_t*)(Lb + a.o_keep) : nullptr;
+    RUN(nbest_internal_attention_fwd8(qkv, key_mask, ctx, ctx8, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream, keepw));
     // attention output projection + dropout + residual, then LayerNorm
     if (f8) {
       RUN(gemm8(ctx8, o.wo, 4 * l + 1, r1, H, H, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), nullptr, nullptr, d->hidden_drop, s0 + 1));
@@ -369,7 +375,8 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     stamp(1);
     // attention backward -> dqkv ; QKV bias gradient
     RUN(nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, f8b ? nullptr : dqkv, G(o.bqkv), accumulate, red3, w.red_bytes, d->B, d->S, d->heads, 64,
-                                      dt, d->attn_drop, d->seed, s0 + 0, stream, fg(dqkv8, 4 * l + 3)));
+                                      dt, d->attn_drop, d->seed, s0 + 0, stream, fg(dqkv8, 4 * l + 3),
+                                      (a.keep_bytes && d->attn_drop > 0.f) ? (const uint32_t*)(Lb + a.o_keep) : nullptr));
     // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
     if (f8b) RUN(dgrad8(dqkv8, 4 * l + 3, o.wqkv, 4 * l + 0, dA, H, 3 * H, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
     else RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));

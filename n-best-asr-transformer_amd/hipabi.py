@@ -17,7 +17,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_DGELU, EPI_RES, EPI_F3
 
 EXPORTS = [
     "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes",
-    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_layernorm_fwd",
+    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
@@ -90,7 +90,7 @@ def lib():
             if not hasattr(L, name):
                 raise RuntimeError("nbest_amd: %s does not export %s" % (LIB_PATH, name))
         for name in ("nbest_embed_bwd_ws_bytes", "nbest_gemm_ws_bytes", "nbest_rowred_ws_bytes", "nbest_heads_ws_bytes",
-                     "nbest_attention_bwd_ws_bytes",
+                     "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes",
                      "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         L.nbest_embed_bwd_ws_bytes.argtypes = [C.c_int64, C.c_int64]
@@ -106,6 +106,9 @@ def lib():
         L.nbest_attention_fwd.argtypes = [vp] * 4 + [i32] * 5 + [f32, u64, u32, vp]
         L.nbest_attention_bwd.argtypes = [vp] * 7 + [i32, vp, sz] + [i32] * 5 + [f32, u64, u32, vp]
         L.nbest_attention_bwd_ws_bytes.argtypes = [i32, i32, i32]
+        L.nbest_attention_keep_bytes.argtypes = [i32, i32, i32]
+        L.nbest_attention_fwd_keep.argtypes = [vp] * 4 + [i32] * 5 + [f32, u64, u32, vp, vp]
+        L.nbest_attention_bwd_keep.argtypes = [vp] * 7 + [i32, vp, sz] + [i32] * 5 + [f32, u64, u32, vp, vp]
         L.nbest_layernorm_fwd.argtypes = [vp] * 5 + [i64, i32, f32, i32, vp]
         L.nbest_layernorm_bwd.argtypes = [vp] * 9 + [i64, i32, i32, i32, f32, u64, u32, vp, sz, vp]
         L.nbest_colsum.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, sz, vp]
@@ -293,18 +296,30 @@ def colsum(X, accumulate=False, out=None):
     return out
 
 
-def attention_fwd(qkv, key_mask, B, S, heads, drop_p=0.0, seed=0, drop_stream=0):
+def attention_fwd(qkv, key_mask, B, S, heads, drop_p=0.0, seed=0, drop_stream=0, want_keep=False):
+    """``want_keep``: also return the dropout keep words for attention_bwd(keep=...) (None where the shape has no such path)"""
     H = heads * 64
     ctx = torch.empty(B * S, H, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, heads, S, dtype=torch.float32, device=qkv.device)
+    if want_keep:
+        nb = lib().nbest_attention_keep_bytes(B, S, heads) if qkv.dtype == torch.bfloat16 else 0
+        keep = torch.zeros(nb // 4, dtype=torch.int32, device=qkv.device) if nb else None
+        check(lib().nbest_attention_fwd_keep(ptr(qkv), ptr(key_mask), ptr(ctx), ptr(lse), B, S, heads, 64, dtype_code(qkv.dtype),
+                                             drop_p, seed, drop_stream, ptr(keep), stream_ptr()), "attention_fwd_keep")
+        return ctx, lse, keep
     check(lib().nbest_attention_fwd(ptr(qkv), ptr(key_mask), ptr(ctx), ptr(lse), B, S, heads, 64, dtype_code(qkv.dtype),
                                     drop_p, seed, drop_stream, stream_ptr()), "attention_fwd")
     return ctx, lse
 
 
-def attention_bwd(qkv, key_mask, ctx, dctx, lse, B, S, heads, drop_p=0.0, seed=0, drop_stream=0, dbias=None):
+def attention_bwd(qkv, key_mask, ctx, dctx, lse, B, S, heads, drop_p=0.0, seed=0, drop_stream=0, dbias=None, keep=None):
     dqkv = torch.empty_like(qkv)
     ws = _ws(lib().nbest_attention_bwd_ws_bytes(B, S, heads), qkv.device) if dbias is not None else None
+    if keep is not None:
+        check(lib().nbest_attention_bwd_keep(ptr(qkv), ptr(key_mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), 0, ptr(ws),
+                                             ws.numel() if ws is not None else 0, B, S, heads, 64, dtype_code(qkv.dtype), drop_p, seed,
+                                             drop_stream, ptr(keep), stream_ptr()), "attention_bwd_keep")
+        return dqkv
     check(lib().nbest_attention_bwd(ptr(qkv), ptr(key_mask), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), 0, ptr(ws),
                                     ws.numel() if ws is not None else 0, B, S, heads, 64, dtype_code(qkv.dtype), drop_p, seed,
                                     drop_stream, stream_ptr()), "attention_bwd")

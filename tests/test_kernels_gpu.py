@@ -316,6 +316,28 @@ def test_attention_dropout_fwd_bwd_consistent(S):
     assert abs(fd - an) <= 2e-2 * max(1.0, abs(fd))
     dq16 = hb.attention_bwd(qkv32.bfloat16(), mask, c16, w.bfloat16(), l16, B, S, heads, drop_p=p, seed=5, drop_stream=9)
     close("attn dropout bf16 vs f32 bwd", dq16, dq, 4e-2)
+    # keep words: the forward hands its dropout decisions to the backward (S <= 256): the words must say what the hash says, and
+    # the backward that reads them must give the re-hashing backward's result
+    c16k, l16k, keep = hb.attention_fwd(qkv32.bfloat16(), mask, B, S, heads, drop_p=p, seed=5, drop_stream=9, want_keep=True)
+    assert torch.equal(c16k, c16) and torch.equal(l16k, l16)
+    if S <= 256:
+        assert keep is not None
+        nkb = (S + 31) // 32
+        kmask, _ = _keep_mask(B * heads * S, S, p, 5, 9)                 # [(bh, q)][key] decisions of the counter stream
+        words = keep.view(B * heads, nkb, nkb * 32)[:, :, :S].to(torch.int64) & 0xFFFFFFFF          # [bh][kb][q]
+        bits = (words.unsqueeze(-1) >> torch.arange(32, device=DEV)) & 1                            # [bh][kb][q][j]
+        got = bits.permute(0, 2, 1, 3).reshape(B * heads, S, nkb * 32)[:, :, :S].bool()
+        bad = (got != kmask.view(B * heads, S, S))
+        assert not bad.any(), "keep words disagree with the counter-based decisions: %d of %d, first at %s" % (
+            int(bad.sum()), bad.numel(), bad.nonzero()[0].tolist())
+        dq16k = hb.attention_bwd(qkv32.bfloat16(), mask, c16, w.bfloat16(), l16, B, S, heads, drop_p=p, seed=5, drop_stream=9, keep=keep)
+        # same decisions; the two kernels differ in how the compiler contracts dp * scale - delta into an fma, so single results
+        # may differ in the last bf16 bit
+        dd = (dq16k.float() - dq16.float()).abs()
+        assert dd.max().item() <= 2.0 ** -7 * dq16.float().abs().max().item() and (dd > 0).float().mean().item() < 0.05, (
+            "keep-word backward differs from the hashing backward: max %.3e, %.2f %% of the elements" % (dd.max().item(), 100 * (dd > 0).float().mean().item()))
+    else:
+        assert keep is None
 
 
 # ------------------------------------------------------------------------------------------------
