@@ -1020,6 +1020,11 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);
   p.stream_out = nb_stream_output(a->M * a->N * 2) ? 1 : 0;
   // B is a weight matrix (k-contiguous [N][K]) in the forward / dgrad GEMMs; the weight gradients have no small operand
+  // B is a weight matrix (k-contiguous [N][K]) in the forward / dgrad GEMMs; the weight gradients have no small operand.
+  // (Column groups re-read the ACTIVATION panel once per group: 490 MB of HBM-side traffic per launch for 277 MB of operands on the
+  // N = 768 dgrads, profiles/r03_pmc.csv - the re-read panel was written by the previous kernel and comes out of the Infinity
+  // Cache.  Same-box sweep of the five N = 768 launches of a layer: 606 / 584 / 578 us with 1 / 2 / 4 tile columns per group - one
+  // column per group loses 4 %, two (the rule's choice at K >= 2304) and row-major tie.)
   p.gn = (!a->trans_a && !a->trans_b) ? nb_group_cols(a->N / pl.bn, (int64_t)pl.bn * a->K * 2, 2400) : (int)(a->N / pl.bn);
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm(bf16): dropout counter overflow");
   const int epi = a->epilogue;

@@ -39,6 +39,13 @@ KERNELS = [
     ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 129024, "weight gradient FFN-up / FFN-down (3072x768 | 768x3072, K = 32 768)", gf(F, H, M), (M * (F + H) * 2 + F * H * 4) / 1e6),
     ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 124416, "weight gradient QKV (2304x768)", gf(3 * H, H, M), (M * 4 * H * 2 + 3 * H * H * 4) / 1e6),
     ("gemm_bf16_kernel<true, true, 6>", None, "weight gradient attention-out (768x768)", gf(H, H, M), (M * 2 * H * 2 + H * H * 4) / 1e6),
+    # round 3: register-epilogue kernels (256 x 256 tiles as 4 x 2 waves; 256 x 192 tiles for the N = 768 shapes)
+    ("gemm2_kernel<256, 192, 4, 2, 4, false, false, 5>", None, "dgrad + residual: QKV (K 2304) | FFN-up (K 3072), N 768 (256x192 tiles)", (gf(M, H, 3 * H) + gf(M, H, F)) / 2, (M * (3 * H + F) / 2 * 2 + 2 * M * H * 2 + (3 * H + F) / 2 * H * 2) / 1e6),
+    ("gemm2_kernel<256, 192, 4, 2, 4, false, false, 3>", None, "forward bias+dropout+residual: attention-out (K 768) | FFN-down (K 3072) (256x192 tiles)", (gf(M, H, H) + gf(M, H, F)) / 2, (M * (H + F) / 2 * 2 + 2 * M * H * 2) / 1e6),
+    ("gemm2_kernel<256, 192, 4, 2, 4, false, false, 0>", None, "dgrad attention-out (256x192 tiles)", gf(M, H, H), (2 * M * H * 2 + H * H * 2) / 1e6),
+    ("gemm2_kernel<256, 256, 4, 2, 4, false, false, 2>", None, "forward FFN-up + bias + GELU (writes GELU and 8-bit GELU')", gf(M, F, H), (M * H * 2 + M * F * 3 + F * H * 2) / 1e6),
+    ("gemm2_kernel<256, 256, 4, 2, 4, false, false, 4>", None, "dgrad FFN-down x GELU' (+ fused db1)", gf(M, F, H), (M * H * 2 + M * F * 3 + F * H * 2) / 1e6),
+    ("gemm2_kernel<256, 256, 4, 2, 4, false, false, 1>", None, "forward QKV + bias", gf(M, 3 * H, H), (M * H * 2 + M * 3 * H * 2 + 3 * H * H * 2) / 1e6),
     ("gemm_bf16_kernel<false, false, 5>", None, "dgrad + residual: QKV (K 2304) | FFN-up (K 3072), N 768", (gf(M, H, 3 * H) + gf(M, H, F)) / 2, (M * (3 * H + F) / 2 * 2 + 2 * M * H * 2 + (3 * H + F) / 2 * H * 2) / 1e6),
     ("gemm_bf16_kernel<false, false, 3>", None, "forward bias+dropout+residual: attention-out (K 768) | FFN-down (K 3072)", (gf(M, H, H) + gf(M, H, F)) / 2, (M * (H + F) / 2 * 2 + 2 * M * H * 2) / 1e6),
     ("gemm2_kernel<256, 256, 2, 4, 4, false, false, 2>", None, "forward FFN-up + bias + GELU (writes GELU and GELU')", gf(M, F, H), (M * H * 2 + 2 * M * F * 2 + F * H * 2) / 1e6),
@@ -57,6 +64,7 @@ KERNELS = [
     ("transpose_multi_kernel", None, "k-contiguous bf16 weight copy for the dgrads", None, 85e6 * 4 / 1e6),
     ("embed_bwd_tables_kernel", None, "embedding backward: position / type tables, LN parameters", None, None),
     ("embed_bwd_kernel", None, "embedding backward: LN-bwd + word-table atomics", None, None),
+    ("rowred_finalize_multi_kernel", None, "partial-row sums of a backward layer -> bias / LayerNorm gradients (one launch per layer)", None, None),
     ("rowred_finalize_kernel", None, "partial-row sums -> bias / LayerNorm gradients", None, None),
 ]
 
