@@ -286,6 +286,15 @@ int nbest_bertadam_chunk(void);
 int nbest_bertadam_step(float* p, float* g, float* m, float* v, void* p_lowp, const nbest_tensor_desc* descs,
                         int n_tensors, int n_blocks, float lr_mult, float b1, float b2, float eps,
                         float max_grad_norm, void* ws, size_t ws_bytes, nbest_stream_t stream);
+/* The same step in two halves over a range of blocks [blk_lo, blk_hi) (new functionality: the optimizer sharded over data-parallel
+ * ranks).  norms: partial[blk] = sum of squares of block blk's gradient elements, for the blocks of the range (the caller zeroes
+ * `partial` [n_blocks] and SUM-all-reduces it over the ranks).  update: clip coefficients of all tensors from `partial`
+ * (coef [n_tensors], scratch), then BertAdam on the blocks of the range.  norms + update over [0, n_blocks) == nbest_bertadam_step. */
+int nbest_bertadam_norms(const float* g, const nbest_tensor_desc* descs, int n_tensors, int n_blocks, int blk_lo, int blk_hi,
+                         float* partial, nbest_stream_t stream);
+int nbest_bertadam_update(float* p, const float* g, float* m, float* v, void* p_lowp, const nbest_tensor_desc* descs,
+                          int n_tensors, int n_blocks, int blk_lo, int blk_hi, const float* partial, float* coef,
+                          float lr_mult, float b1, float b2, float eps, float max_grad_norm, nbest_stream_t stream);
 /* Transposed bf16 copy of the weight matrices (same element offsets in `dst` as in `src`): matrix t is
  * [rows][cols] in src and [cols][rows] in dst.  The backward's dgrad GEMMs read this copy so that both of
  * their operands are k-contiguous (no transposed LDS reads).  descs: DEVICE array ordered by tile_start,

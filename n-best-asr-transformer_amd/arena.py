@@ -201,6 +201,25 @@ class ParamArena:
         return missing
 
     # ---- optimizer descriptors -----------------------------------------------------------------
+    def block_table(self, select=None):
+        """host view of the optimizer's block list for the tensors ``select`` picks (the order of build_descs): one
+        (arena offset, elements, active) triple per block of nbest_bertadam_chunk() elements of one tensor"""
+        chunk = hb.lib().nbest_bertadam_chunk()
+        out = []
+        for s in self.slots:
+            if select is not None and not select(s.name):
+                continue
+            act = 0 if "pooler" in s.name else 1
+            for c0 in range(0, s.numel, chunk):
+                out.append((s.offset + c0, min(chunk, s.numel - c0), act))
+        return out
+
+    def fp32_read_slots(self, select=None):
+        """tensors the kernels read from the fp32 MASTER arena even in the bf16 path (biases, LayerNorm parameters, the STC heads):
+        a data-parallel rank that does not own them needs their updated fp32 values, not the bf16 compute copy"""
+        return [s for s in self.slots if (select is None or select(s.name)) and "pooler" not in s.name and
+                (s.name.startswith("clf.") or s.name.endswith("bias") or "LayerNorm" in s.name)]
+
     def build_descs(self, lr, bert_lr, active=None, select=None):
         """device array of nbest_tensor_desc, one per tensor (grouping of n_best_asr_bert.py:540-550);
         ``select(name)`` restricts the set to some tensors (the optimizer is split so the embedding tables can be

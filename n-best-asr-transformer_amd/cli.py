@@ -234,7 +234,8 @@ def main(argv=None):
     if train is None:
         raise SystemExit("no training split at %s" % os.path.join(opt.dataroot, opt.train_file))
     t_total = (len(train) // opt.batchSize + 1) * opt.max_epoch            # n_best_asr_bert.py:556
-    opt.optimizer = HipBertAdam(model, lr=opt.lr, bert_lr=opt.bert_lr, warmup=opt.warmup_proportion, t_total=t_total)
+    opt.optimizer = HipBertAdam(model, lr=opt.lr, bert_lr=opt.bert_lr, warmup=opt.warmup_proportion, t_total=t_total,
+                                shard=True)      # sharded over the data-parallel ranks (a no-op for one process / the fp8 mode)
     log = _Log(os.path.join(opt.exp_dir, "log.train"), rank, append=opt.resume and os.path.exists(os.path.join(opt.exp_dir, "last.pt")))
     t_start = time.time()
     log.info("Training starts at %s" % time.asctime(time.localtime(t_start)))
@@ -271,6 +272,7 @@ def main(argv=None):
         if vf > best["vf"]:
             best.update(epoch=ep, vf=vf, tef=tef, v_acc=v_acc, te_acc=te_acc)
             if rank == 0:
+                opt.optimizer.gather_master(moments=False)      # sharded optimizer: the fp32 master is current only on each range's owner
                 model.save_model(os.path.join(opt.exp_dir, "model.pt"))
             log.info("NEW BEST:\tEpoch: %02d\tvalid F1/Acc: %.2f/%.2f\ttest F1/Acc: %.2f/%.2f" % (ep, vf, v_acc, tef, te_acc))
         if rank == 0 and opt.resume:

@@ -21,13 +21,14 @@ __device__ __forceinline__ int find_tensor(const nbest_tensor_desc* __restrict__
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, const nbest_tensor_desc* __restrict__ descs,
-                                                    int n_tensors, float* __restrict__ partial) {
+                                                    int n_tensors, float* __restrict__ partial, int blk_off) {
   __shared__ float sm[16];
-  const int t = find_tensor(descs, n_tensors, blockIdx.x);
+  const int blk = blockIdx.x + blk_off;          // a rank of a sharded optimizer runs only its own range of blocks
+  const int t = find_tensor(descs, n_tensors, blk);
   const nbest_tensor_desc d = descs[t];
   float s = 0.f;
   if (d.active) {
-    const int64_t c0 = (int64_t)(blockIdx.x - d.block_start) * kChunk;
+    const int64_t c0 = (int64_t)(blk - d.block_start) * kChunk;
     const int64_t c1 = (c0 + kChunk < d.numel) ? c0 + kChunk : d.numel;
     const float* gp = g + d.offset;
     const bool vec = ((d.offset & 3) == 0);
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     }
   }
   s = block_sum(s, sm);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (threadIdx.x == 0) partial[blk] = s;
 }
 
 // one wave per tensor: coef[t] = min(1, max_norm / (||g_t|| + 1e-6))
@@ -75,13 +76,15 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, bf16* __restrict__ plow,
                                                        const nbest_tensor_desc* __restrict__ descs, int n_tensors,
-                                                       const float* __restrict__ coef, float lr_mult, float b1, float b2, float eps) {
-  const int t = find_tensor(descs, n_tensors, blockIdx.x);
+                                                       const float* __restrict__ coef, float lr_mult, float b1, float b2, float eps,
+                                                       int blk_off) {
+  const int blk = blockIdx.x + blk_off;
+  const int t = find_tensor(descs, n_tensors, blk);
   const nbest_tensor_desc d = descs[t];
   if (!d.active) return;
   const float cf = coef[t];
   const float lr = d.lr * lr_mult;
-  const int64_t c0 = (int64_t)(blockIdx.x - d.block_start) * kChunk;
+  const int64_t c0 = (int64_t)(blk - d.block_start) * kChunk;
   const int64_t c1 = (c0 + kChunk < d.numel) ? c0 + kChunk : d.numel;
   const int64_t base = d.offset;
   const bool vec = ((base & 3) == 0);
@@ -156,19 +159,42 @@ extern "C" int nbest_transpose_weights(const void* src, void* dst, const nbest_m
 
 extern "C" int nbest_bertadam_chunk(void) { return kChunk; }
 
+// The step in its two halves, each over a RANGE of blocks [blk_lo, blk_hi) - the sharded optimizer of the data-parallel path
+// (nbest_amd/optim.py): a rank computes the block sums of squares of its own blocks (`partial` [n_blocks], zero elsewhere; the host
+// SUM-all-reduces it: x + 0 is exact, so every rank ends up with the very numbers a single process computes), then the clip
+// coefficients of ALL tensors (identical on every rank) and the update of its own blocks.
+extern "C" int nbest_bertadam_norms(const float* g, const nbest_tensor_desc* descs, int n_tensors, int n_blocks, int blk_lo, int blk_hi,
+                                    float* partial, nbest_stream_t stream) {
+  NB_CHECK(g && descs && partial && n_tensors > 0 && 0 <= blk_lo && blk_lo <= blk_hi && blk_hi <= n_blocks, NBEST_ERR_ARG,
+           "bertadam_norms: bad arguments");
+  if (blk_hi == blk_lo) return NBEST_OK;
+  sumsq_kernel<<<blk_hi - blk_lo, 256, 0, (hipStream_t)stream>>>(g, descs, n_tensors, partial, blk_lo);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_bertadam_update(float* p, const float* g, float* m, float* v, void* p_lowp, const nbest_tensor_desc* descs,
+                                     int n_tensors, int n_blocks, int blk_lo, int blk_hi, const float* partial, float* coef,
+                                     float lr_mult, float b1, float b2, float eps, float max_grad_norm, nbest_stream_t stream) {
+  NB_CHECK(p && g && m && v && descs && partial && coef && n_tensors > 0 && 0 <= blk_lo && blk_lo <= blk_hi && blk_hi <= n_blocks,
+           NBEST_ERR_ARG, "bertadam_update: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  clip_coef_kernel<<<n_tensors, 64, 0, st>>>(partial, descs, n_tensors, n_blocks, max_grad_norm, coef);
+  NB_LAUNCH_CHECK();
+  if (blk_hi == blk_lo) return NBEST_OK;
+  bertadam_kernel<<<blk_hi - blk_lo, 256, 0, st>>>(p, g, m, v, (bf16*)p_lowp, descs, n_tensors, coef, lr_mult, b1, b2, eps, blk_lo);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
 extern "C" int nbest_bertadam_step(float* p, float* g, float* m, float* v, void* p_lowp, const nbest_tensor_desc* descs,
                                    int n_tensors, int n_blocks, float lr_mult, float b1, float b2, float eps, float max_grad_norm,
                                    void* ws, size_t ws_bytes, nbest_stream_t stream) {
   NB_CHECK(p && g && m && v && descs && ws && n_tensors > 0 && n_blocks > 0, NBEST_ERR_ARG, "bertadam: null pointer");
   NB_CHECK(ws_bytes >= ((size_t)n_blocks + n_tensors) * sizeof(float), NBEST_ERR_WORKSPACE, "bertadam: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)ws;
   float* coef = partial + n_blocks;
-  sumsq_kernel<<<n_blocks, 256, 0, st>>>(g, descs, n_tensors, partial);
-  NB_LAUNCH_CHECK();
-  clip_coef_kernel<<<n_tensors, 64, 0, st>>>(partial, descs, n_tensors, n_blocks, max_grad_norm, coef);
-  NB_LAUNCH_CHECK();
-  bertadam_kernel<<<n_blocks, 256, 0, st>>>(p, g, m, v, (bf16*)p_lowp, descs, n_tensors, coef, lr_mult, b1, b2, eps);
-  NB_LAUNCH_CHECK();
-  return NBEST_OK;
+  if (int rc = nbest_bertadam_norms(g, descs, n_tensors, n_blocks, 0, n_blocks, partial, stream)) return rc;
+  return nbest_bertadam_update(p, g, m, v, p_lowp, descs, n_tensors, n_blocks, 0, n_blocks, partial, coef, lr_mult, b1, b2, eps,
+                               max_grad_norm, stream);
 }

@@ -19,7 +19,7 @@ EXPORTS = [
     "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes",
     "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
-    "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step",
+    "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
     "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_wgrad_fp8", "nbest_wgrad_fp8_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
 ]
@@ -117,6 +117,8 @@ def lib():
         L.nbest_cls_grad_scatter.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.nbest_stc_decode.argtypes = [vp, vp, C.POINTER(LabelSpaceC), vp, vp, i32, vp]
         L.nbest_bertadam_step.argtypes = [vp] * 6 + [i32, i32, f32, f32, f32, f32, f32, vp, sz, vp]
+        L.nbest_bertadam_norms.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+        L.nbest_bertadam_update.argtypes = [vp] * 6 + [i32, i32, i32, i32, vp, vp, f32, f32, f32, f32, f32, vp]
         L.nbest_cast_f32_to_bf16.argtypes = [vp, vp, i64, vp]
         L.nbest_encoder_forward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 7 + [sz, vp, sz, C.POINTER(C.c_void_p), vp]
         L.nbest_encoder_backward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 9 + [sz, vp, vp, sz, i32, i32, i32, i32, vp]

@@ -85,8 +85,12 @@ class GradReducer:
     then every rank's rows added in rank order, so all replicas perform the same additions in the same order and stay
     bit-identical.  Position / token-type tables and the embedding LayerNorm stay in a (small) dense bucket."""
 
-    def __init__(self, arena, n_chunks=6, sparse_word_grad=None):
+    def __init__(self, arena, n_chunks=6, sparse_word_grad=None, owner_ranges=None):
+        """``owner_ranges`` (optim.HipBertAdam(shard=True).owner_ranges): per rank, the arena ranges it owns under the sharded
+        optimizer - every bucket then travels as a REDUCE of its intersection with each owner's range to that owner (half the bytes
+        of the all-reduce; the non-owners never read those gradients) instead of a SUM all-reduce."""
         self.arena = arena
+        self.owner_ranges = owner_ranges
         self.rank, self.world = dist_info()
         L = len(arena.layer_range)
         n_chunks = max(1, min(n_chunks, L))
@@ -171,9 +175,17 @@ class GradReducer:
 
     # ---- dense buckets -------------------------------------------------------------------------------------------------
     def _launch(self, lo, hi, last=False):
-        if dist.is_available() and dist.is_initialized() and hi > lo:
-            w = dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
-            (self.pending_emb if last else self.pending).append(w)
+        if not (dist.is_available() and dist.is_initialized() and hi > lo):
+            return
+        todo = self.pending_emb if last else self.pending
+        if self.owner_ranges is None:
+            todo.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            return
+        for r, ranges in enumerate(self.owner_ranges):          # the same sequence of collectives on every rank
+            for olo, ohi in ranges:
+                a, b = max(lo, olo), min(hi, ohi)
+                if b > a:
+                    todo.append(dist.reduce(self.arena.g[a:b], dst=r, op=dist.ReduceOp.SUM, async_op=True))
 
     def layers_ready(self, l_lo, l_hi):
         if not self.pending and not self.pending_emb:
@@ -449,7 +461,8 @@ def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
     only the micro-batch that closes a group exchanges gradients."""
     model.train()
     rank, world = dist_info()
-    reducer = GradReducer(model.arena) if (dist.is_available() and dist.is_initialized()) else None
+    reducer = (GradReducer(model.arena, owner_ranges=getattr(opt.optimizer, "owner_ranges", None))
+               if (dist.is_available() and dist.is_initialized()) else None)
     counts, losses = (0, 0, 0, 0, 0), []
     split = encoded(data, opt, memory)
     n_accum = max(1, int(getattr(opt, "n_accum_steps", 1) or 1))

@@ -108,6 +108,18 @@ def _worker(rank, world, port, q):
     else:
         red3.contribute_nothing()
         ok = ok and torch.equal(a.g[:ws.numel], both[0][:ws.numel])
+    # sharded optimizer: every bucket travels as a REDUCE of its intersection with each owner's arena range to that owner
+    a.g.copy_(local)
+    cut = a.layer_range[1][1] - 1000                        # an ownership boundary inside a layer (and inside a bucket)
+    emb_cut = a.emb_range[1] // 2
+    owners = [[(a.layer_range[0][0], cut), (0, emb_cut)], [(cut, a.total), (emb_cut, a.emb_range[1])]]
+    red4 = trainer.GradReducer(a, n_chunks=3, owner_ranges=owners)
+    for lo_, hi_ in sorted(red4.chunks, reverse=True):
+        red4.layers_ready(lo_, hi_)
+    red4.wait()
+    for lo_, hi_ in owners[rank]:
+        seg = covered[lo_:hi_]                              # (pooler slots are in no bucket)
+        ok = ok and torch.allclose(a.g[lo_:hi_][seg], want[lo_:hi_][seg], atol=1e-6)
     # eval cases: every rank holds its slice of each batch; merged list = dataset order on every rank
     mine = [(b, rank, [("b%d" % b, "r%d" % rank, i) for i in range(2 - rank + b % 2)]) for b in range(3)]
     merged = trainer.merge_cases(mine)

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 LOG = os.path.join(ROOT, "gpurun_out", "dp_equivalence.log")
 
 
-def _worker(rank, world, port, B, sparse, q):
+def _worker(rank, world, port, B, sparse, q, dtype_name="float32"):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -41,11 +41,13 @@ def _worker(rank, world, port, B, sparse, q):
         cfg = ncfg.bert_base(num_hidden_layers=4, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
         S, STEPS, LR = 48, 3, 1e-3
 
-        def build(seed):
-            m = NBestSTCModel(cfg, labels, device="cuda:0", compute_dtype=torch.float32, dropout=0.0)
+        cdt = getattr(torch, dtype_name)
+
+        def build(seed, shard=False):
+            m = NBestSTCModel(cfg, labels, device="cuda:0", compute_dtype=cdt, dropout=0.0)
             m.load_reference_state(synth.model_state(cfg, labels, seed=seed))
             m.train()
-            return m, HipBertAdam(m, lr=LR, bert_lr=LR, warmup=0.1, t_total=10)
+            return m, HipBertAdam(m, lr=LR, bert_lr=LR, warmup=0.1, t_total=10, shard=shard)
 
         batches = []
         for s in range(STEPS):
@@ -73,6 +75,44 @@ def _worker(rank, world, port, B, sparse, q):
         torch.cuda.synchronize()
         got = m.arena.p.clone()
         rec_dp, _, _ = _finish(losses, (0, 0, 0, 0, 0), "cpu", STEPS)
+
+        # control: the replicated path a second time (is the step itself bit-reproducible from run to run?)
+        mc, optc = build(seed=5 + rank)
+        broadcast_parameters(mc)
+        redc = GradReducer(mc.arena, n_chunks=2, sparse_word_grad=sparse)
+        for b in batches:
+            train_step(mc, optc, shard(b), add_l2_loss=True, add_segment_ids=True, reducer=redc, global_batch=B)
+        torch.cuda.synchronize()
+        gotc = mc.arena.p.clone()
+
+        # the SHARDED optimizer (gradients reduced to the owner of each arena range, every rank updates its own range, owners
+        # broadcast the compute copy): same start, same shards, same steps
+        m2, opt2 = build(seed=5 + rank, shard=True)
+        assert opt2.sharded and len(opt2.owner_ranges) == world
+        broadcast_parameters(m2)
+        red2 = GradReducer(m2.arena, n_chunks=2, sparse_word_grad=sparse, owner_ranges=opt2.owner_ranges)
+        for b in batches:
+            train_step(m2, opt2, shard(b), add_l2_loss=True, add_segment_ids=True, reducer=red2, global_batch=B)
+        torch.cuda.synchronize()
+        ws0 = m.arena.by_name["bert_encoder.embeddings.word_embeddings.weight"]
+        w_same = torch.equal(m2.arena.weights[ws0.offset + ws0.numel:], m.arena.weights[ws0.offset + ws0.numel:])   # what the next step would read
+        opt2.gather_master()
+        torch.cuda.synchronize()
+        got2 = m2.arena.p.clone()
+        # the word-embedding table's gradient is summed with fp32 atomics (order varies from run to run: two runs of the SAME
+        # optimizer differ there in the last bit), so bit-equality is asked of everything else: layers, heads, position / type tables
+        ws_ = m.arena.by_name["bert_encoder.embeddings.word_embeddings.weight"]
+        rest = torch.ones(got.numel(), dtype=torch.bool, device=got.device)
+        rest[ws_.offset:ws_.offset + ws_.numel] = False
+        wd = (got2 - got)[~rest].abs()
+        sh = dict(equal=torch.equal(got2[rest], got[rest]), weights_equal=w_same, max=(got2 - got)[rest].abs().max().item(),
+                  mean=(got2 - got).abs().mean().item(), word_max=wd.max().item(), word_mean=wd.mean().item(),
+                  m_equal=torch.equal(m2.arena.m[rest], m.arena.m[rest]), owned=[r_ for r_ in opt2.owner_ranges[rank]],
+                  ctrl_equal=torch.equal(gotc[rest], got[rest]), ctrl_max=(gotc - got)[rest].abs().max().item())
+        g2h = got2.cpu()
+        all2 = [torch.zeros_like(g2h) for _ in range(world)]
+        dist.all_gather(all2, g2h)
+        sh["replicas_same"] = all(torch.equal(all2[0], x) for x in all2)
 
         # one process on the whole batch (every rank computes it redundantly)
         ms, opts = build(seed=5)
@@ -105,19 +145,23 @@ def _worker(rank, world, port, B, sparse, q):
         mean_err = (got - want).abs().mean().item()
         dist.destroy_process_group()
         q.put((rank, dict(gerr=gerr, same=same, mean_err=mean_err, max_err=(got - want).abs().max().item(), rec_dp=rec_dp,
-                          rec_one=rec_one, rows=rows if rank == 0 else None)))
+                          rec_one=rec_one, rows=rows if rank == 0 else None, sharded=sh)))
     except BaseException as e:                      # surface the failure in the parent instead of a queue timeout
         import traceback
         q.put((rank, dict(error=traceback.format_exc() + repr(e))))
 
 
-@pytest.mark.parametrize("world,B,sparse", [(2, 5, False), (3, 7, True)])
-def test_dp_step_equals_single_process(world, B, sparse):
-    """sparse: the word-embedding gradient travels as (row ids, row values) instead of through the dense all-reduce"""
+@pytest.mark.parametrize("world,B,sparse,dtype_name", [(2, 5, False, "float32"), (3, 7, True, "float32"), (2, 6, False, "bfloat16")])
+def test_dp_step_equals_single_process(world, B, sparse, dtype_name):
+    """sparse: the word-embedding gradient travels as (row ids, row values) instead of through the dense all-reduce.
+    Every case also runs the SHARDED optimizer (HipBertAdam(shard=True) + reduce-to-owner) next to the replicated one: its
+    replicas must be bit-identical, and its parameters equal the replicated path's - to the last bit where the gradient sum has
+    two terms (world 2: a + b is the same number whichever collective forms it), to summation-order noise at world 3.  The
+    bfloat16 case checks exactly that on the production dtype (bf16 compute copy + fp32 small tensors broadcast by the owners)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29620 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B, sparse, q)) for r in range(world)]
+    port = 29620 + world + (7 if dtype_name != "float32" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, sparse, q, dtype_name)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in procs)
@@ -128,8 +172,8 @@ def test_dp_step_equals_single_process(world, B, sparse):
     r0 = res[0]
     os.makedirs(os.path.dirname(LOG), exist_ok=True)
     with open(LOG, "a") as f:
-        f.write("world %d, batch %d (uneven shards), fp32, 4 layers, lr 1e-3, 3 BertAdam steps, word-embedding gradient exchange: %s\n" % (
-            world, B, "sparse rows" if sparse else "dense all-reduce"))
+        f.write("world %d, batch %d (uneven shards), %s, 4 layers, lr 1e-3, 3 BertAdam steps, word-embedding gradient exchange: %s\n" % (
+            world, B, dtype_name, "sparse rows" if sparse else "dense all-reduce"))
         f.write("  reduced-shard gradient vs whole-batch gradient: max relative difference %.2e (bound 2e-5)\n" % r0["gerr"])
         f.write("  parameters: mean |DP - single| %.2e (bound 2e-6), max %.2e; replicas bit-identical: %s\n" % (
             r0["mean_err"], r0["max_err"], all(res[r]["same"] for r in range(world))))
@@ -137,8 +181,22 @@ def test_dp_step_equals_single_process(world, B, sparse):
         f.write("  %-64s %10s %10s %10s %s\n" % ("tensor", "grad rel", "max |dp|", "mean |dp|", "share of elements off by > 1% of lr"))
         for name, ge, mx, mean, share in sorted(r0["rows"], key=lambda t: -t[2])[:12]:
             f.write("  %-64s %10.2e %10.2e %10.2e %.2e\n" % (name[-64:], ge, mx, mean, share))
+        sh = r0["sharded"]
+        f.write("  sharded optimizer vs replicated (word table aside: its gradient is summed with atomics): parameters bit-equal %s (max |d| %.2e), "
+                "compute copy bit-equal %s, moments bit-equal %s, replicas bit-identical %s; word table max |d| %.2e mean %.2e; rank 0 owns %s\n" % (
+                    sh["equal"], sh["max"], sh["weights_equal"], sh["m_equal"], all(res[r]["sharded"]["replicas_same"] for r in range(world)),
+                    sh["word_max"], sh["word_mean"], sh["owned"]))
+        f.write("  control - the replicated path run twice: bit-equal %s (max |d| %.2e)\n" % (sh["ctrl_equal"], sh["ctrl_max"]))
     for r in range(world):
+        sh = res[r]["sharded"]
+        assert sh["replicas_same"], "sharded replicas diverged"
+        if world == 2 and sh["ctrl_equal"]:
+            assert sh["equal"] and sh["weights_equal"], ("sharded optimizer differs from the replicated one", sh)
+        else:                              # no tighter than two runs of the replicated path agree with each other
+            assert sh["mean"] < 2e-6 and sh["max"] <= max(10 * sh["ctrl_max"], 1e-4), sh
         assert res[r]["same"], "replicas diverged"
+        if dtype_name != "float32":
+            continue                       # the single-process comparison below carries fp32 bars
         assert res[r]["gerr"] < 2e-5, res[r]["gerr"]
         assert res[r]["mean_err"] < 2e-6, res[r]["mean_err"]
         assert abs(res[r]["rec_dp"] - res[r]["rec_one"]) <= 1e-5 * abs(res[r]["rec_one"]), (res[r]["rec_dp"], res[r]["rec_one"])
