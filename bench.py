@@ -152,21 +152,23 @@ def time_wgrad_in_step(model, step, B, S, n_steps=3, operand_bytes=2.0):
     torch.cuda.synchronize()
     arr = (C.c_void_p * n_ev)(*[e.cuda_event for e in evs])
     desc = model._pass(B, S, 0).desc
+    from nbest_amd import hipabi as hb
+    per_layer = hb.lib().nbest_encoder_wgrad_launches_per_layer(C.byref(desc))   # 3: QKV + attention-out share a launch (bf16)
     desc.wgrad_events, desc.wgrad_events_n = C.cast(arr, C.POINTER(C.c_void_p)), n_ev
     tot, n = 0.0, 0
     try:
         for _ in range(n_steps):
             step()
             torch.cuda.synchronize()
-            for i in range(4 * L):
+            for i in range(per_layer * L):
                 tot += evs[2 * i].elapsed_time(evs[2 * i + 1])
                 n += 1
     finally:
         desc.wgrad_events, desc.wgrad_events_n = None, 0
     shapes = [(H, F), (F, H), (H, H), (3 * H, H)]
-    flops = sum(2.0 * M * a * b for a, b in shapes) / 4
-    byts = sum(operand_bytes * M * (a + b) + 4.0 * a * b for a, b in shapes) / 4
-    return tot / n, flops, byts
+    flops = sum(2.0 * M * a * b for a, b in shapes) / per_layer
+    byts = sum(operand_bytes * M * (a + b) + 4.0 * a * b for a, b in shapes) / per_layer
+    return tot / n, flops, byts, per_layer
 
 
 def note(msg):
@@ -288,20 +290,23 @@ def main():
         if a.dtype in ("bf16", "fp8w") and not a.no_roofline:
             f8 = a.dtype == "fp8w"
             peak = PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS
-            ms, fl, by = time_wgrad_in_step(model, step, a.batch, a.seq_len, operand_bytes=1.0 if f8 else 2.0)
+            ms, fl, by, wpl = time_wgrad_in_step(model, step, a.batch, a.seq_len, operand_bytes=1.0 if f8 else 2.0)
             ach = fl / (ms * 1e-3) / 1e12
             traffic, src = wgrad_traffic_from_profiles(f8) if (a.model == "bert" and a.batch == 256 and a.seq_len == 128) else (None, "not measured for this shape")
             H_, F_ = cfg.hidden_size, cfg.intermediate_size
             kern = ("gemm8tt_kernel (e4m3 x e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, ds_read_b64_tr_b8 transposed reads) + splitk_reduce8_kernel" if f8 else
+                    "gemm2_kernel<256,256,...,true,true,F32_SPLITK> + splitk_reduce2_kernel; the QKV and attention-output gradients of a layer "
+                    "share one launch (nbest_wgrad_pair: 27 + 9 output tiles)" if wpl == 3 else
                     "gemm2_kernel<256,256,...,true,true,F32_SPLITK> for QKV/FFN, gemm_bf16_kernel<true,true,F32_SPLITK> for the attention "
                     "output, each followed by its split-K reduce")
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": src,
                                "kernel": "weight-gradient GEMM dW = dY^T.X (both operands token-major, transposed LDS reads, split-K, fp32 "
-                                         "out; %s), K = %d token rows; avg over the 4 launches of a layer: %dx%d, %dx%d, %dx%d, %dx%d" % (
-                                             kern, a.batch * a.seq_len, H_, F_, F_, H_, H_, H_, 3 * H_, H_),
+                                         "out; %s), K = %d token rows; avg over the %d launches of a layer: %dx%d, %dx%d, %s" % (
+                                             kern, a.batch * a.seq_len, wpl, H_, F_, F_, H_,
+                                             "%dx%d + %dx%d" % (3 * H_, H_, H_, H_) if wpl == 3 else "%dx%d, %dx%d" % (H_, H_, 3 * H_, H_)),
                                "timing": "HIP events recorded by the library around each of the %d launches per step, on the launch "
-                                         "stream, inside 3 training steps run right after the timed region" % (4 * cfg.num_hidden_layers),
+                                         "stream, inside 3 training steps run right after the timed region" % (wpl * cfg.num_hidden_layers),
                                "avg_launch_ms": round(ms, 4), "flops_per_launch": fl, "algorithmic_bytes_per_launch": by}
         if world == 1 and not a.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")

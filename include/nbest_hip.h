@@ -113,6 +113,17 @@ typedef struct nbest_gemm_args {
 size_t nbest_gemm_ws_bytes(const nbest_gemm_args* a);
 int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream);
 
+/* Two weight gradients dW = dY^T . X (bf16 operands, trans_a = trans_b = 1, NBEST_EPI_F32_SPLITK) that share the token dimension K
+ * and the column count N, in ONE launch: the 256 x 256 output tiles of `b` are appended to those of `a`, every tile takes the same
+ * K-splits and one reduce launch writes both gradients (a->C and b->C; a->ws / a->ws_bytes hold the slabs of both:
+ * >= nbest_wgrad_pair_ws_bytes).  Used by nbest_encoder_backward for the QKV ([3H, H]) and attention-output ([H, H]) gradients of
+ * a layer - the backward of the two nn.Linear of installed modeling_bert.py:154-177 / 282-293 - whose tile counts (27 + 9) add up to
+ * the FFN gradients' (36): the small gradient no longer runs as a launch of 9 tiles x 28 splits of its own.  Results equal
+ * nbest_gemm's on each problem up to the fp32 summation order over K-splits.  M1, M2, N multiples of 256, same `accumulate`;
+ * nbest_wgrad_pair_ws_bytes returns 0 and nbest_wgrad_pair NBEST_ERR_SHAPE for pairs that do not fit (issue two nbest_gemm).   */
+size_t nbest_wgrad_pair_ws_bytes(const nbest_gemm_args* a, const nbest_gemm_args* b);
+int nbest_wgrad_pair(const nbest_gemm_args* a, const nbest_gemm_args* b, nbest_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * fp8 forward GEMMs (dtype path NBEST "fp8w": BASELINE configs[4], "fp8 weights (CDNA4 fp8 MFMA)")
  * C[M][N] (bf16) = epi((A8[M][K] . W8[N][K]^T) * out_scale + bias): both operands OCP e4m3 (one byte per element, k-contiguous),
@@ -340,8 +351,9 @@ typedef struct nbest_encoder_desc {
   int32_t wgrad_events_n;    /* entries of wgrad_events (0 = no timing) */
   /* optional in-step timing of the weight-gradient GEMMs (bench.py's roofline object): caller-created hipEvent_t
    * handles; nbest_encoder_backward records wgrad_events[2*i] before and [2*i+1] after the i-th weight-gradient
-   * launch it enqueues (4 per layer, highest layer first: FFN-down, FFN-up, attention-out, QKV), on the caller's
-   * stream, while i < wgrad_events_n / 2.  The library never creates, waits on or destroys events.            */
+   * launch it enqueues (nbest_encoder_wgrad_launches_per_layer() per layer, highest layer first: FFN-down, FFN-up,
+   * attention-out, QKV - or, bf16, FFN-down, FFN-up, QKV + attention-out as one nbest_wgrad_pair launch), on the
+   * caller's stream, while i < wgrad_events_n / 2.  The library never creates, waits on or destroys events.      */
   void** wgrad_events;
   /* optional fp8 forward ("fp8w"; dtype must be NBEST_BF16): e4m3 copy of the weight arena (one byte per element at the
    * same element offsets) and its per-matrix inverse scales [4 L] (QKV, attention-out, FFN-up, FFN-down per layer), both
@@ -362,6 +374,9 @@ typedef struct nbest_encoder_desc {
 } nbest_encoder_desc;
 size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
 size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);
+/* weight-gradient launches nbest_encoder_backward enqueues per layer for this descriptor: 3 when the attention-output gradient
+ * rides with the QKV gradient (nbest_wgrad_pair; bf16, shapes that fit), else 4 */
+int nbest_encoder_wgrad_launches_per_layer(const nbest_encoder_desc* d);
 /* hidden_out: pointer to the final hidden states [M][H] inside act (returned through *hidden_out) */
 int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wts, const float* prm, const int64_t* ids,
                           const int64_t* seg, const int64_t* pos, const uint8_t* key_mask, void* act,

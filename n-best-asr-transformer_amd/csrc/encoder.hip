@@ -97,7 +97,24 @@ static size_t max_splitk_bytes(const nbest_encoder_desc* d, int64_t M) {
       if (b8 > mx) mx = b8;
     }
   }
+  if (d->dtype == NBEST_BF16) {   // the QKV + attention-output pair (nbest_wgrad_pair)
+    nbest_gemm_args g1 = {}, g2 = {};
+    g1.M = 3 * (int64_t)d->H; g2.M = d->H; g1.N = g2.N = d->H; g1.K = g2.K = M;
+    g1.trans_a = g1.trans_b = g2.trans_a = g2.trans_b = 1; g1.epilogue = g2.epilogue = NBEST_EPI_F32_SPLITK; g1.dtype = g2.dtype = NBEST_BF16;
+    const size_t bp = nbest_wgrad_pair_ws_bytes(&g1, &g2);
+    if (bp > mx) mx = bp;
+  }
   return mx;
+}
+
+// bf16 (not the fp8 backward): the attention-output weight gradient of a layer is issued together with the QKV gradient
+// (nbest_wgrad_pair: 3 weight-gradient launches per layer instead of 4) when the pair fits one 256 x 256 split-K launch
+static bool wgrad_paired(const nbest_encoder_desc* d, bool f8b) {
+  if (d->dtype != NBEST_BF16 || f8b) return false;
+  nbest_gemm_args g1 = {}, g2 = {};
+  g1.M = 3 * (int64_t)d->H; g2.M = d->H; g1.N = g2.N = d->H; g1.K = g2.K = (int64_t)d->B * d->S;
+  g1.trans_a = g1.trans_b = g2.trans_a = g2.trans_b = 1; g1.epilogue = g2.epilogue = NBEST_EPI_F32_SPLITK; g1.dtype = g2.dtype = NBEST_BF16;
+  return nbest_wgrad_pair_ws_bytes(&g1, &g2) > 0;
 }
 
 static WsLayout ws_layout(const nbest_encoder_desc* d) {
@@ -187,6 +204,9 @@ static int gemm(int dtype, const void* A, const void* B, void* C, int64_t M, int
 
 extern "C" size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d) { return d ? act_layout(d).total : 0; }
 extern "C" size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d) { return d ? ws_layout(d).total : 0; }
+extern "C" int nbest_encoder_wgrad_launches_per_layer(const nbest_encoder_desc* d) {
+  return d ? (wgrad_paired(d, fp8_backward_active(d)) ? 3 : 4) : 0;
+}
 
 extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wts, const float* prm, const int64_t* ids,
                                      const int64_t* seg, const int64_t* pos, const uint8_t* key_mask, void* act, size_t act_bytes,
@@ -297,7 +317,9 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   void* red1 = W + w.red + w.red_bytes; void* red2 = W + w.red + 2 * w.red_bytes; void* red3 = W + w.red + 3 * w.red_bytes;
   const uint32_t sb = d->drop_stream_base;
   // optional in-step timing of the weight-gradient GEMMs (see nbest_encoder_desc::wgrad_events)
-  int ev_i = 4 * (d->L - layer_end);
+  const bool f8b = fp8_backward_active(d);
+  const bool paired = wgrad_paired(d, f8b);
+  int ev_i = (paired ? 3 : 4) * (d->L - layer_end);
   auto stamp = [&](int which) {
     if (d->wgrad_events && 2 * ev_i + which < d->wgrad_events_n) (void)hipEventRecord((hipEvent_t)d->wgrad_events[2 * ev_i + which], st);
     ev_i += which;
@@ -306,7 +328,6 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   // fp8 dgrads (descriptor: w8t, gamax_prev / gamax_new, fp8_bwd): the gradient amax of every dgrad operand is recorded in
   // every pass; with a history (fp8_bwd) the producers also write e4m3 copies and the four dgrad GEMMs of a layer run in fp8
   const bool rec = d->gamax_new && dt == NBEST_BF16;
-  const bool f8b = fp8_backward_active(d);
   uint8_t* dqkv8 = f8b ? (uint8_t*)W + w.f8 : nullptr;                       // [M][3H]
   uint8_t* dBig8 = f8b ? dqkv8 + 3 * al((size_t)M * H) : nullptr;            // [M][F]
   uint8_t* dRd8 = f8b ? dBig8 + al((size_t)M * F) : nullptr;                 // [M][H]
@@ -368,11 +389,14 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     // attention output projection: dgrad ; wgrad
     if (f8b) RUN(dgrad8(dRd8, 4 * l + 2, o.wo, 4 * l + 1, dctx, H, H, NBEST_EPI_NONE, nullptr, nullptr, nullptr, -1, nullptr));
     else RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
-    stamp(0);
-    if (f8b) RUN(nbest_wgrad_fp8(dRd8, ctx8, G(o.wo), H, H, M, H, H, H, d->gamax_prev + 4 * l + 2, accumulate, slab, w.slab_bytes, stream));
-    else RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
-                  accumulate, 0.f, 0, 0, st));
-    stamp(1);
+    // (bf16: this layer's dRd and ctx stay untouched until the next layer's LayerNorm backward - the gradient is issued below, with QKV's)
+    if (!paired) {
+      stamp(0);
+      if (f8b) RUN(nbest_wgrad_fp8(dRd8, ctx8, G(o.wo), H, H, M, H, H, H, d->gamax_prev + 4 * l + 2, accumulate, slab, w.slab_bytes, stream));
+      else RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
+                    accumulate, 0.f, 0, 0, st));
+      stamp(1);
+    }
     // attention backward -> dqkv ; QKV bias gradient
     RUN(nbest_internal_attention_bwd8(qkv, key_mask, ctx, dctx, lse, f8b ? nullptr : dqkv, G(o.bqkv), accumulate, red3, w.red_bytes, d->B, d->S, d->heads, 64,
                                       dt, d->attn_drop, d->seed, s0 + 0, stream, fg(dqkv8, 4 * l + 3),
@@ -382,7 +406,15 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     else RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
     stamp(0);
     if (f8b) RUN(nbest_wgrad_fp8(dqkv8, x8, G(o.wqkv), 3 * H, H, M, 3 * H, H, H, d->gamax_prev + 4 * l + 3, accumulate, slab, w.slab_bytes, stream));
-    else RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
+    else if (paired) {
+      nbest_gemm_args g1 = {}, g2 = {};
+      g1.A = dqkv; g1.B = X(l); g1.C = G(o.wqkv); g1.M = 3 * H; g1.lda = 3 * H;
+      g2.A = dRd; g2.B = ctx; g2.C = G(o.wo); g2.M = H; g2.lda = H;
+      g1.N = g2.N = H; g1.K = g2.K = M; g1.ldb = g2.ldb = g1.ldc = g2.ldc = H;
+      g1.trans_a = g1.trans_b = g2.trans_a = g2.trans_b = 1; g1.epilogue = g2.epilogue = NBEST_EPI_F32_SPLITK;
+      g1.dtype = g2.dtype = dt; g1.accumulate = g2.accumulate = accumulate; g1.ws = slab; g1.ws_bytes = w.slab_bytes;
+      RUN(nbest_wgrad_pair(&g1, &g2, stream));
+    } else RUN(gemm(dt, dqkv, X(l), G(o.wqkv), 3 * H, H, M, 3 * H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab,
                   w.slab_bytes, accumulate, 0.f, 0, 0, st));
     stamp(1);
     RUN(nbest_internal_rowred_batch_flush(st));

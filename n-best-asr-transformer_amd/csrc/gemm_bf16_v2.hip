@@ -47,6 +47,11 @@ struct GemmP2 {
   DropCfg drop;
   int stream_out;     // epilogue stores are nontemporal (common.h st_stream)
   int gn;             // tile columns per L2 group (common.h nb_tile_coords)
+  // second problem of a weight-gradient PAIR (nbest_wgrad_pair): output rows >= m_split of the virtual [M][N] result are
+  // A2^T . B2 (same K and N); m_split = 0: none
+  const bf16* A2; const bf16* B2;
+  int64_t lda2, ldb2, m_split;
+  uint32_t a2_bytes, b2_bytes;
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
@@ -175,8 +180,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
   const int nk = (int)((kend - kbeg + BK - 1) / BK);
 
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  // operands of this tile: the second problem's for the tiles below m_split of a weight-gradient pair (workgroup-uniform)
+  const bf16* opA = p.A; const bf16* opB = p.B;
+  int64_t lda_ = p.lda, ldb_ = p.ldb, m0a = m0;
+  uint32_t a_bytes = p.a_bytes, b_bytes = p.b_bytes;
+  if constexpr (TA && TB && EPI == NBEST_EPI_F32_SPLITK) {
+    if (p.m_split > 0 && m0 >= p.m_split) {
+      opA = p.A2; opB = p.B2; lda_ = p.lda2; ldb_ = p.ldb2; m0a = m0 - p.m_split; a_bytes = p.a2_bytes; b_bytes = p.b2_bytes;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)opB, 0, b_bytes, 0x00020000);
 
   // epilogue operands that do not depend on the K loop
   constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES);
@@ -258,8 +272,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
-        stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0, kbeg + (int64_t)s0 * BK, p.lda, tid);
-        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, p.ldb, tid, lds + STAGES * STAGE);
+        stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0a, kbeg + (int64_t)s0 * BK, lda_, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, ldb_, tid, lds + STAGES * STAGE);
       }
     }
     {
@@ -280,8 +294,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         int nb = buf + STAGES - 1;
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
-        stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid, lds + STAGES * STAGE);
+        stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0a, k0, lda_, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, ldb_, tid, lds + STAGES * STAGE);
       }
       const char* cur = lds + buf * STAGE;
       if ((DIAG & 2) == 0 || kt == 0) {
@@ -341,8 +355,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
   for (int s = 0; s < STAGES; ++s) {
     if (s < nk) {
-      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
-      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s * STAGE, m0a, kbeg + (int64_t)s * BK, lda_, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, ldb_, tid);
     }
   }
   bf16x8 afA[TMt], bfA[TNt], afB[TMt], bfB[TNt];
@@ -374,8 +388,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     asm volatile("" ::: "memory");                                                                           \
     if (kt + STAGES < nk) {                                                                                  \
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES) * BK;                                                 \
-      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + buf * STAGE, m0, k0, p.lda, tid);                                       \
-      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, p.ldb, tid);                             \
+      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + buf * STAGE, m0a, k0, lda_, tid);                                       \
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, ldb_, tid);                             \
     }                                                                                                        \
     const int nbuf = (buf + 1 == STAGES) ? 0 : buf + 1;                                                      \
     if (kt + 1 < nk) {                                                                                       \
@@ -402,8 +416,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s) {
     if (s < nk) {
-      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s * STAGE, m0, kbeg + (int64_t)s * BK, p.lda, tid);
-      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, p.ldb, tid);
+      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s * STAGE, m0a, kbeg + (int64_t)s * BK, lda_, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s * STAGE + A_BYTES, n0, kbeg + (int64_t)s * BK, ldb_, tid);
     }
   }
   int buf = 0;
@@ -419,8 +433,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       int nb = buf + STAGES - 1;
       if (nb >= STAGES) nb -= STAGES;
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
-      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid, lds + STAGES * STAGE);
+      stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0a, k0, lda_, tid);
+      stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, ldb_, tid, lds + STAGES * STAGE);
     }
     const char* cur = lds + buf * STAGE;
     bf16x8 af[TMt], bfr[TNt];
@@ -825,13 +839,15 @@ __global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
 
 #endif  // NBEST_EXPERIMENTS
 
+// rows >= m_split of the slabs' [M][N] image belong to the second output of a weight-gradient pair (C2, ldc2); m_split = M: none
 __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float* __restrict__ slab, float* __restrict__ C, int64_t MN,
-                                                             int64_t N, int64_t ldc, int splits, int accumulate) {
+                                                             int64_t N, int64_t ldc, int splits, int accumulate,
+                                                             float* __restrict__ C2, int64_t m_split, int64_t ldc2) {
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * blockDim.x * 4) {
     f32x4 s = *(const f32x4*)(slab + i);
     for (int z = 1; z < splits; ++z) s += *(const f32x4*)(slab + (int64_t)z * MN + i);
     const int64_t m = i / N, n = i - m * N;
-    float* c = C + m * ldc + n;
+    float* c = (m < m_split) ? C + m * ldc + n : C2 + (m - m_split) * ldc2 + n;
     if (accumulate) s += *(const f32x4*)c;
     *(f32x4*)c = s;
   }
@@ -980,7 +996,9 @@ size_t nbest_gemm_bf16_v2_ws_bytes(const nbest_gemm_args* a) {
   return pl.splits > 1 ? (size_t)pl.splits * a->M * a->N * sizeof(float) : 0;
 }
 
-int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
+// `b2` (with `a` = the VIRTUAL problem of M1 + M2 output rows carrying the first problem's pointers, m_split = M1): the second
+// problem of a weight-gradient pair, see nbest_wgrad_pair_bf16
+static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int64_t m_split, hipStream_t st) {
   NB_CHECK(a->N % 64 == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld must be a multiple of 64", (long long)a->N);
   NB_CHECK(a->trans_a || a->K % BK == 0, NBEST_ERR_SHAPE, "gemm(bf16): K=%lld must be a multiple of %d", (long long)a->K, BK);
   NB_CHECK(!(a->trans_a && !a->trans_b), NBEST_ERR_ARG, "gemm(bf16): trans_a without trans_b is not built");
@@ -999,15 +1017,23 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
   p.accumulate = a->accumulate;
   p.slab = (float*)a->ws;
   p.colpart = nullptr;
+  p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.m_split = 0; p.a2_bytes = p.b2_bytes = 0;
   if (a->colsum_out && a->epilogue != NBEST_EPI_F32_SPLITK) {
     NB_CHECK(a->ws && a->ws_bytes >= nbest_gemm_bf16_v2_ws_bytes(a), NBEST_ERR_WORKSPACE, "gemm: column-sum workspace too small");
     p.colpart = (float*)a->ws;
   }
-  const int64_t a_rows = a->trans_a ? a->K : a->M, a_cols = a->trans_a ? a->M : a->K;
+  const int64_t a_rows = a->trans_a ? a->K : a->M, a_cols = a->trans_a ? (b2 ? m_split : a->M) : a->K;
   const int64_t b_rows = a->trans_b ? a->K : a->N, b_cols = a->trans_b ? a->N : a->K;
   const int64_t ab = ((a_rows - 1) * a->lda + a_cols) * 2, bb = ((b_rows - 1) * a->ldb + b_cols) * 2;
   NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm(bf16): operand larger than 4 GiB");
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  if (b2) {
+    const int64_t ab2 = ((a->K - 1) * b2->lda + b2->M) * 2, bb2 = ((a->K - 1) * b2->ldb + a->N) * 2;
+    NB_CHECK(ab2 < ((int64_t)1 << 32) && bb2 < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm(bf16): operand larger than 4 GiB");
+    p.A2 = (const bf16*)b2->A; p.B2 = (const bf16*)b2->B; p.lda2 = b2->lda; p.ldb2 = b2->ldb; p.m_split = m_split;
+    p.a2_bytes = (uint32_t)ab2; p.b2_bytes = (uint32_t)bb2;
+    NB_CHECK(pl.bm == 256 && pl.bn == 256 && pl.splits > 1 && m_split % 256 == 0, NBEST_ERR_SHAPE, "wgrad pair: not a 256 x 256 split-K plan");
+  }
   p.c_bytes = p.r_bytes = p.u_bytes = 0;
   if (a->epilogue != NBEST_EPI_F32_SPLITK) {   // 32-bit byte offsets, also for the rows of a ragged last tile (dropped by the range check)
     const int64_t mpad = a->M + 256;
@@ -1083,8 +1109,39 @@ int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) {
     const int64_t MN = a->M * a->N;
     int64_t g = (MN / 4 + 255) / 256;
     if (g > 2048) g = 2048;
-    splitk_reduce2_kernel<<<(int)g, 256, 0, st>>>(p.slab, (float*)a->C, MN, a->N, a->ldc, p.splits, a->accumulate);
+    splitk_reduce2_kernel<<<(int)g, 256, 0, st>>>(p.slab, (float*)a->C, MN, a->N, a->ldc, p.splits, a->accumulate,
+                                                  b2 ? (float*)b2->C : nullptr, b2 ? m_split : a->M, b2 ? b2->ldc : 0);
     NB_LAUNCH_CHECK();
   }
   return NBEST_OK;
+}
+
+int nbest_gemm_bf16_v2(const nbest_gemm_args* a, hipStream_t st) { return gemm_v2_impl(a, nullptr, 0, st); }
+
+// Two weight gradients with the same K (token rows) and N in ONE launch: the output tiles of the second are appended below the
+// first's (a virtual [M1 + M2][N] result; its slabs are reduced into the two gradients by one reduce launch).  The 768 x 768
+// attention-output gradient (9 tiles of 256 x 256: 28 K-splits on its own) rides with the 2304 x 768 QKV gradient (27 tiles):
+// 36 tiles x 7 splits = the FFN gradients' launch shape.  Returns NBEST_ERR_SHAPE when the pair does not fit the 256 x 256 plan
+// (the caller then issues the two GEMMs separately).
+static bool pair_virtual(const nbest_gemm_args* a, const nbest_gemm_args* b, nbest_gemm_args* v) {
+  if (a->dtype != NBEST_BF16 || b->dtype != NBEST_BF16 || !a->trans_a || !a->trans_b || !b->trans_a || !b->trans_b) return false;
+  if (a->epilogue != NBEST_EPI_F32_SPLITK || b->epilogue != NBEST_EPI_F32_SPLITK) return false;
+  if (a->N != b->N || a->K != b->K || a->accumulate != b->accumulate || a->M % 256 || b->M % 256 || a->N % 256) return false;
+  if ((a->flags | b->flags) & NBEST_GEMM_DEFER_REDUCE) return false;
+  *v = *a;
+  v->M = a->M + b->M;
+  const Plan pl = make_plan(v);
+  return pl.bm == 256 && pl.bn == 256 && pl.splits > 1;
+}
+size_t nbest_wgrad_pair_bf16_ws_bytes(const nbest_gemm_args* a, const nbest_gemm_args* b) {
+  nbest_gemm_args v;
+  if (!pair_virtual(a, b, &v)) return 0;
+  return nbest_gemm_bf16_v2_ws_bytes(&v);
+}
+int nbest_wgrad_pair_bf16(const nbest_gemm_args* a, const nbest_gemm_args* b, hipStream_t st) {
+  nbest_gemm_args v;
+  NB_CHECK(pair_virtual(a, b, &v), NBEST_ERR_SHAPE, "wgrad pair: the two problems do not share one 256 x 256 split-K launch");
+  NB_CHECK(b->lda % 8 == 0 && b->ldb % 8 == 0 && b->ldc % 8 == 0 && ((uintptr_t)b->A & 15) == 0 && ((uintptr_t)b->B & 15) == 0 &&
+               ((uintptr_t)b->C & 15) == 0, NBEST_ERR_ALIGN, "wgrad pair: second problem misaligned");
+  return gemm_v2_impl(&v, b, a->M, st);
 }

@@ -166,3 +166,21 @@ extern "C" int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream) {
   nbest_set_error("gemm: bad dtype %d", a->dtype);
   return NBEST_ERR_DTYPE;
 }
+
+// ---- two weight gradients, one launch (include/nbest_hip.h) ------------------------------------------------------------
+size_t nbest_wgrad_pair_bf16_ws_bytes(const nbest_gemm_args* a, const nbest_gemm_args* b);
+int nbest_wgrad_pair_bf16(const nbest_gemm_args* a, const nbest_gemm_args* b, hipStream_t st);
+
+extern "C" size_t nbest_wgrad_pair_ws_bytes(const nbest_gemm_args* a, const nbest_gemm_args* b) {
+  if (!a || !b) return 0;
+  return nbest_wgrad_pair_bf16_ws_bytes(a, b);
+}
+
+extern "C" int nbest_wgrad_pair(const nbest_gemm_args* a, const nbest_gemm_args* b, nbest_stream_t stream) {
+  NB_CHECK(a && b && a->A && a->B && a->C && b->A && b->B && b->C, NBEST_ERR_ARG, "wgrad_pair: null pointer");
+  NB_CHECK(a->M > 0 && b->M > 0 && a->N > 0 && a->K > 0, NBEST_ERR_SHAPE, "wgrad_pair: bad shape");
+  NB_CHECK(nbest_wgrad_pair_bf16_ws_bytes(a, b) > 0, NBEST_ERR_SHAPE,
+           "wgrad_pair: needs two bf16 F32_SPLITK problems (trans_a = trans_b = 1) with equal N, K and accumulate, M1, M2, N multiples of 256 "
+           "and at least 18 output tiles in all");
+  return nbest_wgrad_pair_bf16(a, b, (hipStream_t)stream);
+}

@@ -17,10 +17,10 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_DGELU, EPI_RES, EPI_F3
 
 EXPORTS = [
     "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes",
-    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
+    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_wgrad_pair_ws_bytes", "nbest_wgrad_pair", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
-    "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_forward",
+    "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_wgrad_launches_per_layer", "nbest_encoder_forward",
     "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_wgrad_fp8", "nbest_wgrad_fp8_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
 ]
 
@@ -89,7 +89,7 @@ def lib():
         for name in EXPORTS:
             if not hasattr(L, name):
                 raise RuntimeError("nbest_amd: %s does not export %s" % (LIB_PATH, name))
-        for name in ("nbest_embed_bwd_ws_bytes", "nbest_gemm_ws_bytes", "nbest_rowred_ws_bytes", "nbest_heads_ws_bytes",
+        for name in ("nbest_embed_bwd_ws_bytes", "nbest_gemm_ws_bytes", "nbest_wgrad_pair_ws_bytes", "nbest_rowred_ws_bytes", "nbest_heads_ws_bytes",
                      "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes",
                      "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
@@ -98,8 +98,11 @@ def lib():
         L.nbest_heads_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         L.nbest_gemm_ws_bytes.argtypes = [C.POINTER(GemmArgs)]
         L.nbest_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+        L.nbest_wgrad_pair_ws_bytes.argtypes = [C.POINTER(GemmArgs), C.POINTER(GemmArgs)]
+        L.nbest_wgrad_pair.argtypes = [C.POINTER(GemmArgs), C.POINTER(GemmArgs), C.c_void_p]
         L.nbest_encoder_act_bytes.argtypes = [C.POINTER(EncoderDesc)]
         L.nbest_encoder_ws_bytes.argtypes = [C.POINTER(EncoderDesc)]
+        L.nbest_encoder_wgrad_launches_per_layer.argtypes = [C.POINTER(EncoderDesc)]
         vp, i64, i32, f32, u64, u32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
         L.nbest_embed_ln_fwd.argtypes = [vp] * 10 + [i64, i32, f32, i32, f32, u64, u32, vp]
         L.nbest_embed_ln_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, i32, i64, i64, i32, f32, u64, u32, vp, sz, vp]
@@ -217,6 +220,29 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=No
     g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
     check(lib().nbest_gemm(C.byref(g), stream_ptr()), "gemm")
     return (out, U) if epilogue == EPI_BIAS_GELU else out
+
+
+def wgrad_pair(dY1, X1, dY2, X2, out1=None, out2=None, accumulate=False):
+    """(dY1^T . X1, dY2^T . X2) in fp32 by ONE launch (nbest_wgrad_pair): dY_i [K, M_i], X_i [K, N] bf16, token-major"""
+    K, N = X1.shape
+    outs, gs = [], []
+    for dY, X, out in ((dY1, X1, out1), (dY2, X2, out2)):
+        M = dY.shape[1]
+        if out is None:
+            out = torch.empty(M, N, dtype=torch.float32, device=X.device)
+        g = GemmArgs()
+        g.A, g.B, g.C = dY.data_ptr(), X.data_ptr(), out.data_ptr()
+        g.M, g.N, g.K = M, N, K
+        g.lda, g.ldb, g.ldc = dY.stride(0), X.stride(0), out.stride(0)
+        g.trans_a = g.trans_b = 1
+        g.epilogue, g.dtype, g.accumulate = EPI_F32_SPLITK, dtype_code(X.dtype), int(accumulate)
+        outs.append(out)
+        gs.append(g)
+    nb = lib().nbest_wgrad_pair_ws_bytes(C.byref(gs[0]), C.byref(gs[1]))
+    ws = _ws(nb, X1.device)
+    gs[0].ws, gs[0].ws_bytes = ws.data_ptr(), ws.numel()
+    check(lib().nbest_wgrad_pair(C.byref(gs[0]), C.byref(gs[1]), stream_ptr()), "wgrad_pair")
+    return outs
 
 
 def gelu_d_decode(U):

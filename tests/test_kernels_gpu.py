@@ -108,6 +108,32 @@ def test_gemm_bf16_bert_shapes():
               dY.float().t() @ A.float(), 1e-2)
 
 
+@pytest.mark.parametrize("H,K,acc", [(768, 4096 + 40, False), (768, 32768, True), (1024, 2048, False)])
+def test_wgrad_pair_equals_two_weight_gradients(H, K, acc):
+    """nbest_wgrad_pair: the QKV ([3H, H]) and attention-output ([H, H]) weight gradients of a layer in ONE launch (36 / 64 tiles of
+    256 x 256, one set of K-splits, one reduce).  Against the fp32 products of the same bf16 operands, and against the two separate
+    nbest_gemm launches it replaces (the same numbers up to the fp32 summation order over K-splits); operands with their own leading
+    dimensions (dQ|dK|dV rows of 3H, the others H), a token count that is not a multiple of the K-step, and accumulate."""
+    bf = torch.bfloat16
+    dqkv, x = rnd(K, 3 * H, dtype=bf, seed=1), rnd(K, H, dtype=bf, seed=2)
+    dy, ctx = rnd(K, H, dtype=bf, seed=3), rnd(K, H, dtype=bf, seed=4)
+    base1, base2 = rnd(3 * H, H, seed=5), rnd(H, H, seed=6)
+    o1, o2 = (base1.clone(), base2.clone()) if acc else (None, None)
+    g1, g2 = hb.wgrad_pair(dqkv, x, dy, ctx, out1=o1, out2=o2, accumulate=acc)
+    r1, r2 = dqkv.float().t() @ x.float(), dy.float().t() @ ctx.float()
+    if acc:
+        r1, r2 = r1 + base1, r2 + base2
+    close("wgrad pair QKV  H=%d K=%d" % (H, K), g1, r1, 2e-5)
+    close("wgrad pair attn H=%d K=%d" % (H, K), g2, r2, 2e-5)
+    s1 = hb.gemm(dqkv, x, 3 * H, H, K, 1, 1, hb.EPI_F32_SPLITK, out=base1.clone() if acc else None, accumulate=acc)
+    s2 = hb.gemm(dy, ctx, H, H, K, 1, 1, hb.EPI_F32_SPLITK, out=base2.clone() if acc else None, accumulate=acc)
+    close("wgrad pair vs separate QKV", g1, s1, 2e-6)
+    close("wgrad pair vs separate attn", g2, s2, 2e-6)
+    # a pair that does not fit (N not a multiple of 256) is refused, not silently mis-tiled
+    with pytest.raises(RuntimeError):
+        hb.wgrad_pair(rnd(512, 384, dtype=bf), rnd(512, 128, dtype=bf), rnd(512, 128, dtype=bf), rnd(512, 128, dtype=bf))
+
+
 def _keep_mask(M, N, p, seed, stream):
     """Independent restatement of the counter-based dropout decision (csrc/common.h nb_mix_key / nb_hash32 / nb_keep):
     element idx = m * N + n is kept iff the 16-bit half of hash32((idx >> 1) * 0x9E3779B9 + key) selected by idx & 1 is >= thr16."""
