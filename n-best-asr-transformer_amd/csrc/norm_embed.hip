@@ -463,35 +463,43 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   }
 }
 
-// backward A: LN backward per row, de -> de_buf (fp32) and atomically into dword; dgamma/dbeta partials
+// Embedding backward, ONE kernel: LayerNorm backward per row -> de (fp32, registers only); de is added atomically into the
+// word-table row of the token, and summed IN REGISTERS for the position table, the token-type rows 0 / 1 and the LayerNorm
+// parameter gradients.  Block (j, y) owns sequence position j for the samples b = y, y + Y, ...: every row it sees has the same
+// position key (pos[b * S + j] == pos[j]: BERT's arange; for the RoBERTa family the same except padding rows, whose key is the
+// padding row and carries no gradient), so the position gradient never leaves the registers until one atomic add per block and
+// column.  Rows with another key / token type >= 2 fall back to row atomics.  (Before: a second kernel re-read a 100 MB fp32 copy
+// of de to form the position / type sums - 135 us at 14 % of the HBM rate, on top of the 100 MB write.)
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
                                                         const int64_t* __restrict__ pos, const T* __restrict__ word,
                                                         const T* __restrict__ type, const T* __restrict__ ptab,
                                                         const float* __restrict__ gamma, const float* __restrict__ stats,
                                                         const T* __restrict__ dout, float* __restrict__ dword,
-                                                        float* __restrict__ de_buf, float* __restrict__ part, int64_t M,
-                                                        int H, int rows_per_block, int64_t word_pad_id, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];  // [2][H] column partials | [waves][H] row restage
+                                                        float* __restrict__ dtype_tab, float* __restrict__ dptab,
+                                                        float* __restrict__ part, int B, int S, int H, int n_types,
+                                                        int64_t word_pad_id, int64_t pos_pad_id, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [5][H] column sums (dgamma, dbeta, position, type 0, type 1) | [waves][H] row restage
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, nvec = H >> 2;
   const float invH = 1.0f / (float)H;
-  float* rowbuf = acc + 2 * H + wave * H;
-  for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) acc[i] = 0.f;
+  float* rowbuf = acc + 5 * H + wave * H;
+  for (int i = threadIdx.x; i < 5 * H; i += blockDim.x) acc[i] = 0.f;
   __syncthreads();
-  f32x4 ag[VPL], ab[VPL], gm[VPL];
+  f32x4 ag[VPL], ab[VPL], gm[VPL], ap[VPL], t0[VPL], t1[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    ag[i] = ab[i] = f32x4{0, 0, 0, 0};
+    ag[i] = ab[i] = ap[i] = t0[i] = t1[i] = f32x4{0, 0, 0, 0};
     const int c = lane + 64 * i;
     gm[i] = (c < nvec) ? *(const f32x4*)(gamma + 4 * c) : f32x4{0, 0, 0, 0};
   }
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
-  for (int64_t row = r0 + wave; row < r1; row += wpb) {
-    const int64_t id = ids[row];
+  const int j = blockIdx.x;
+  const int64_t key0 = pos[j];
+  for (int b = blockIdx.y + gridDim.y * wave; b < B; b += gridDim.y * wpb) {
+    const int64_t row = (int64_t)b * S + j;
+    const int64_t id = ids[row], key = pos[row], sv = seg ? seg[row] : 0;
     const T* wr = word + id * H;
-    const T* tr = type + (seg ? seg[row] : 0) * H;
-    const T* pr = ptab + pos[row] * H;
+    const T* tr = type + sv * H;
+    const T* pr = ptab + key * H;
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     f32x4 xh[VPL], g[VPL], d[VPL];
     float s1 = 0.f, s2 = 0.f;
@@ -516,25 +524,36 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     }
     s1 = wave_sum(s1) * invH;
     s2 = wave_sum(s2) * invH;
+    const bool own_key = (key == key0), t_is0 = (sv == 0), t_is1 = (sv == 1);   // wave-uniform
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + 64 * i;
       if (c < nvec) {
         f32x4 o = (g[i] - s1 - xh[i] * s2) * rstd;
-        *(f32x4*)(de_buf + row * H + 4 * c) = o;
         *(f32x4*)(rowbuf + 4 * c) = o;
         ag[i] += d[i] * xh[i];
         ab[i] += d[i];
+        if (own_key) ap[i] += o;
+        if (t_is0) t0[i] += o;
+        if (t_is1) t1[i] += o;
       }
     }
-    // scatter-add into the word table with lane-contiguous columns: every atomic wave-instruction covers 256
-    // contiguous bytes of one table row (the shape that runs at the full float-atomic rate)
+    // scatter-add with lane-contiguous columns: every atomic wave-instruction covers 256 contiguous bytes of one table
+    // row (the shape that runs at the full float-atomic rate)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (id != word_pad_id) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       float* dw = dword + id * H;
       for (int col = lane; col < H; col += 64) atomicAdd(dw + col, rowbuf[col]);
-      asm volatile("" ::: "memory");
     }
+    if (!own_key && key != pos_pad_id) {
+      float* dp = dptab + key * H;
+      for (int col = lane; col < H; col += 64) atomicAdd(dp + col, rowbuf[col]);
+    }
+    if (!t_is0 && !t_is1) {
+      float* dtp = dtype_tab + sv * H;
+      for (int col = lane; col < H; col += 64) atomicAdd(dtp + col, rowbuf[col]);
+    }
+    asm volatile("" ::: "memory");
   }
   for (int w = 0; w < wpb; ++w) {   // waves take turns (no LDS float atomics, see ln_bwd_kernel)
     if (wave == w) {
@@ -544,59 +563,21 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
         if (c < nvec) {
           *(f32x4*)&acc[4 * c] += ag[i];
           *(f32x4*)&acc[H + 4 * c] += ab[i];
+          *(f32x4*)&acc[2 * H + 4 * c] += ap[i];
+          *(f32x4*)&acc[3 * H + 4 * c] += t0[i];
+          *(f32x4*)&acc[4 * H + 4 * c] += t1[i];
         }
       }
     }
     __syncthreads();
   }
-  const int nblk = gridDim.x;
+  const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
-    part[((int64_t)0 * nblk + blockIdx.x) * H + i] = acc[i];
-    part[((int64_t)1 * nblk + blockIdx.x) * H + i] = acc[H + i];
-  }
-}
-
-// backward B: position / token-type table gradients.  Block j owns sequence position j and sums de
-// over the batch in registers for the common key (pos[0*S+j]); rows with another key fall back to
-// atomics.  Token types 0/1 are summed in registers too.  Results are atomically ADDED to the tables.
-__global__ __launch_bounds__(256) void embed_bwd_tables_kernel(const int64_t* __restrict__ seg, const int64_t* __restrict__ pos,
-                                                               const float* __restrict__ de_buf, float* __restrict__ dtype_tab,
-                                                               float* __restrict__ dptab, int B, int S, int H, int n_types,
-                                                               int64_t pos_pad_id) {
-  const int j = blockIdx.x;
-  const int nvec = H >> 2;
-  for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
-    f32x4 ap = {0, 0, 0, 0}, t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
-    const int64_t key0 = pos[j];
-    for (int b = blockIdx.y; b < B; b += gridDim.y) {   // the batch is split over blockIdx.y: S blocks alone leave half the chip idle
-      const int64_t m = (int64_t)b * S + j;
-      const f32x4 de = *(const f32x4*)(de_buf + m * H + 4 * c);
-      const int64_t key = pos[m];
-      if (key == key0) ap += de;
-      else if (key != pos_pad_id) {
-        float* p = dptab + key * H + 4 * c;
-        atomicAdd(p, de[0]); atomicAdd(p + 1, de[1]); atomicAdd(p + 2, de[2]); atomicAdd(p + 3, de[3]);
-      }
-      const int64_t sv = seg ? seg[m] : 0;
-      if (sv == 0) t0 += de;
-      else if (sv == 1) t1 += de;
-      else {
-        float* p = dtype_tab + sv * H + 4 * c;
-        atomicAdd(p, de[0]); atomicAdd(p + 1, de[1]); atomicAdd(p + 2, de[2]); atomicAdd(p + 3, de[3]);
-      }
-    }
-    if (key0 != pos_pad_id) {
-      float* p = dptab + key0 * H + 4 * c;
-      atomicAdd(p, ap[0]); atomicAdd(p + 1, ap[1]); atomicAdd(p + 2, ap[2]); atomicAdd(p + 3, ap[3]);
-    }
-    {
-      float* p = dtype_tab + 4 * c;
-      atomicAdd(p, t0[0]); atomicAdd(p + 1, t0[1]); atomicAdd(p + 2, t0[2]); atomicAdd(p + 3, t0[3]);
-    }
-    if (n_types > 1) {
-      float* p = dtype_tab + H + 4 * c;
-      atomicAdd(p, t1[0]); atomicAdd(p + 1, t1[1]); atomicAdd(p + 2, t1[2]); atomicAdd(p + 3, t1[3]);
-    }
+    part[((int64_t)0 * nblk + bid) * H + i] = acc[i];
+    part[((int64_t)1 * nblk + bid) * H + i] = acc[H + i];
+    if (key0 != pos_pad_id) atomicAdd(dptab + key0 * H + i, acc[2 * H + i]);
+    atomicAdd(dtype_tab + i, acc[3 * H + i]);
+    if (n_types > 1) atomicAdd(dtype_tab + H + i, acc[4 * H + i]);
   }
 }
 
@@ -736,7 +717,8 @@ extern "C" size_t nbest_rowred_ws_bytes(int64_t M, int64_t N) {
   return (size_t)3 * b * N * sizeof(float);
 }
 extern "C" size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H) {
-  return nbest_rowred_ws_bytes(M, H) + (size_t)M * H * sizeof(float);
+  (void)M;
+  return (size_t)3 * kMaxLnBwdBlocks * H * sizeof(float);   // partial rows of the LayerNorm-parameter gradients (<= kMaxLnBwdBlocks blocks)
 }
 
 // y8 != NULL (bf16, H % 256 == 0, H <= 1024 only): also write the e4m3 copy of y that the next fp8 forward GEMM reads
@@ -884,25 +866,31 @@ extern "C" int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const 
   NB_CHECK(ws_bytes >= nbest_embed_bwd_ws_bytes(M, H), NBEST_ERR_WORKSPACE, "embed_ln_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const DropCfg d = make_drop(drop_p, seed, drop_stream);
-  const int nblk = rowred_blocks(M);
-  const int rpb = (int)((M + nblk - 1) / nblk);
+  // S x Y blocks (position, batch slice): as many as the partial-row workspace holds (kMaxLnBwdBlocks), at most one per sample
+  int Y = kMaxLnBwdBlocks / S;
+  if (Y > B) Y = B;
+  if (Y < 1) Y = 1;
+  NB_CHECK((int64_t)S * Y <= kMaxLnBwdBlocks || Y == 1, NBEST_ERR_SHAPE, "embed_ln_bwd: bad grid");
+  NB_CHECK(S <= kMaxLnBwdBlocks, NBEST_ERR_SHAPE, "embed_ln_bwd: S = %d exceeds %d", S, kMaxLnBwdBlocks);
+  const int nblk = S * Y;
   float* part = (float*)ws;
-  float* de_buf = (float*)((char*)ws + nbest_rowred_ws_bytes(M, H));
-  const size_t smem = (size_t)(2 + 4) * H * sizeof(float);
+  const size_t smem = (size_t)(5 + 4) * H * sizeof(float);
+  const dim3 grid(S, Y);
   if (dtype == NBEST_F32) {
-    DISPATCH_VPL(H, (embed_bwd_kernel<float, VPL><<<nblk, 256, smem, st>>>(ids, seg, pos, (const float*)word, (const float*)type,
+    DISPATCH_VPL(H, ((void)hipFuncSetAttribute((const void*)embed_bwd_kernel<float, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
+                     embed_bwd_kernel<float, VPL><<<grid, 256, smem, st>>>(ids, seg, pos, (const float*)word, (const float*)type,
                                                                             (const float*)ptab, gamma, stats, (const float*)dout, dword,
-                                                                            de_buf, part, M, H, rpb, word_pad_id, d)));
+                                                                            dtype_tab, dptab, part, B, S, H, n_types, word_pad_id,
+                                                                            pos_pad_id, d)));
   } else if (dtype == NBEST_BF16) {
-    DISPATCH_VPL(H, (embed_bwd_kernel<bf16, VPL><<<nblk, 256, smem, st>>>(ids, seg, pos, (const bf16*)word, (const bf16*)type,
+    DISPATCH_VPL(H, ((void)hipFuncSetAttribute((const void*)embed_bwd_kernel<bf16, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
+                     embed_bwd_kernel<bf16, VPL><<<grid, 256, smem, st>>>(ids, seg, pos, (const bf16*)word, (const bf16*)type,
                                                                            (const bf16*)ptab, gamma, stats, (const bf16*)dout, dword,
-                                                                           de_buf, part, M, H, rpb, word_pad_id, d)));
+                                                                           dtype_tab, dptab, part, B, S, H, n_types, word_pad_id,
+                                                                           pos_pad_id, d)));
   } else NB_CHECK(false, NBEST_ERR_DTYPE, "embed_ln_bwd: bad dtype %d", dtype);
   NB_LAUNCH_CHECK();
-  if (int e = finalize(part, nblk, H, dgamma, accumulate, dbeta, accumulate, nullptr, 0, st)) return e;
-  embed_bwd_tables_kernel<<<dim3(S, B >= 64 ? 8 : 1), 256, 0, st>>>(seg, pos, de_buf, dtype_tab, dptab, B, S, H, n_types, pos_pad_id);
-  NB_LAUNCH_CHECK();
-  return NBEST_OK;
+  return finalize(part, nblk, H, dgamma, accumulate, dbeta, accumulate, nullptr, 0, st);
 }
 
 extern "C" int nbest_cls_grad_scatter(const float* dcls, void* dhidden, int B, int S, int H, int dtype,

@@ -62,7 +62,7 @@ KERNELS = [
     ("splitk_reduce2_kernel", None, "split-K reduce of a weight gradient", None, None),
     ("splitk_reduce_kernel", None, "split-K reduce (768x768)", None, None),
     ("transpose_multi_kernel", None, "k-contiguous bf16 weight copy for the dgrads", None, 85e6 * 4 / 1e6),
-    ("embed_bwd_tables_kernel", None, "embedding backward: position / type tables, LN parameters", None, None),
+    ("embed_bwd_tables_kernel", None, "embedding backward: position / type tables, LN parameters (folded into embed_bwd_kernel in round 3)", None, None),
     ("embed_bwd_kernel", None, "embedding backward: LN-bwd + word-table atomics", None, None),
     ("rowred_finalize_multi_kernel", None, "partial-row sums of a backward layer -> bias / LayerNorm gradients (one launch per layer)", None, None),
     ("rowred_finalize_kernel", None, "partial-row sums -> bias / LayerNorm gradients", None, None),
