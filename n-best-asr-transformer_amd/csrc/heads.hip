@@ -24,34 +24,82 @@ __device__ __forceinline__ int layer_of_row(int r, const int32_t* __restrict__ h
   return lay;
 }
 
+// The 1 + n_heads dropout masks of a step (one per linear layer of the hierarchical classifier, each over [B][H]) are hashed ONCE
+// and kept as bits: mw[(layer * B + b) * W + (h >> 5)], W = ceil(H / 32) words per row.  Every head row of a layer shares its
+// layer's mask, so hashing per (row, b, h) in the three kernels below repeated the same 14-instruction decision R / n_layers = 14
+// times (34 M hashes per kernel at B = 256); the bits are the same decisions (nb_keep), so nothing changes numerically.
+__device__ __forceinline__ void heads_mask_words(const DropCfg& drop, int lay, int b, int B, int H, int W, uint32_t* lds_row,
+                                                 uint32_t* __restrict__ glob_row) {
+  const int lane = threadIdx.x & 63;
+  for (int h0 = (threadIdx.x & ~63); h0 < H; h0 += blockDim.x) {
+    const int h = h0 + lane;
+    const bool keep = (h < H) && nb_keep(drop, (uint32_t)((lay * B + b) * H + h));
+    const uint64_t bal = __ballot(keep);
+    if (lane == 0) {
+      const int w = h0 >> 5;
+      lds_row[w] = (uint32_t)bal;
+      if (w + 1 < W) lds_row[w + 1] = (uint32_t)(bal >> 32);
+      if (glob_row) {
+        glob_row[w] = (uint32_t)bal;
+        if (w + 1 < W) glob_row[w + 1] = (uint32_t)(bal >> 32);
+      }
+    }
+  }
+}
+
 // logits[b][r] = sum_h Wh[r][h] * drop_{layer(r)}(cls[b][h]) + bh[r];  grid (B, kLogitSplit), block 256:
-// blockIdx.y owns a contiguous slice of the head rows (more, shorter blocks: the kernel is latency bound)
+// blockIdx.y owns a contiguous slice of the head rows (more, shorter blocks: the kernel is latency bound).  A block hashes the
+// masks of the layers its rows belong to into LDS; the blockIdx.y == 0 block of a sample hashes all of them and also writes
+// them to `mw` for the two gradient kernels.
 constexpr int kLogitSplit = 8;
+// (Measured: 1024-thread blocks make the three GEMV-like kernels of the heads slower - 67 / 33 / 48 us against 46 / 39 / 29.)
+constexpr int kHeadsThreads = 256;
 template <typename T>
-__global__ __launch_bounds__(256) void heads_logits_kernel(const T* __restrict__ hidden, int64_t cls_stride,
+__global__ __launch_bounds__(kHeadsThreads) void heads_logits_kernel(const T* __restrict__ hidden, int64_t cls_stride,
                                                            const float* __restrict__ Wh, const float* __restrict__ bh,
                                                            const int32_t* __restrict__ head_row, int n_top, int R, int H,
                                                            float* __restrict__ cls_out, float* __restrict__ logits,
+                                                           uint32_t* __restrict__ mw, int32_t* __restrict__ lay_row, int n_lay,
                                                            DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [H]
-  const int b = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [H] | mask words [n_lay][W] | layer of row [R]
+  const int b = blockIdx.x, B = gridDim.x, W = (H + 31) >> 5;
+  uint32_t* mk = (uint32_t*)(xs + H);
+  int32_t* lay_s = (int32_t*)(mk + n_lay * W);
   const T* x = hidden + (int64_t)b * cls_stride;
   for (int h = threadIdx.x; h < H; h += blockDim.x) {
     const float v = to_f<T>(x[h]);
     xs[h] = v;
     if (blockIdx.y == 0) cls_out[(int64_t)b * H + h] = v;
   }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int per = (R + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * per, r1 = (r0 + per < R) ? r0 + per : R;
+  // layer_of_row walks head_row with dependent loads (microseconds): once per row, all rows in parallel, then LDS lookups; the
+  // first block also publishes the table for the gradient kernels
+  const bool first = (blockIdx.x == 0 && blockIdx.y == 0);
+  for (int r = (first ? 0 : r0) + (int)threadIdx.x; r < (first ? R : r1); r += blockDim.x) {
+    const int l = layer_of_row(r, head_row, n_top, nullptr);
+    lay_s[r] = l;
+    if (first) lay_row[r] = l;
+  }
+  __syncthreads();
+  if (drop.thr16) {
+    const bool all = (blockIdx.y == 0);
+    const int la = all ? 0 : (r0 < r1 ? lay_s[r0] : 0);
+    const int lb = all ? n_lay - 1 : (r0 < r1 ? lay_s[r1 - 1] : -1);
+    for (int lay = la; lay <= lb; ++lay)
+      heads_mask_words(drop, lay, b, B, H, W, mk + lay * W, all ? mw + ((int64_t)lay * B + b) * W : nullptr);
+  }
+  __syncthreads();
   for (int r = r0 + wave; r < r1; r += nw) {
-    const int lay = layer_of_row(r, head_row, n_top, nullptr);
+    const int lay = lay_s[r];
     const float* w = Wh + (int64_t)r * H;
+    const uint32_t* mrow = mk + lay * W;
     float s = 0.f;
+#pragma unroll 16
     for (int h = lane; h < H; h += 64) {
       float xv = xs[h];
-      if (drop.thr16) xv = nb_keep(drop, (uint32_t)((lay * gridDim.x + b) * H + h)) ? xv * drop.scale : 0.f;
+      if (drop.thr16) xv = ((mrow[h >> 5] >> (h & 31)) & 1u) ? xv * drop.scale : 0.f;
       s = fmaf(w[h], xv, s);
     }
     s = wave_sum(s);
@@ -169,23 +217,25 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
 }
 
 // dWh[r][h] = sum_b dz[b][r] * drop(cls[b][h]); dbh[r] = sum_b dz[b][r].  grid (R, ceil(H/64)), block 256:
-// a block owns one head row x 64 columns (lane = column), its four waves split the batch; thousands of
-// short waves hide the load latency that a few long ones could not.  Fixed-order LDS reduce (deterministic).
-__global__ __launch_bounds__(256) void heads_wgrad_kernel(const float* __restrict__ cls, const float* __restrict__ dz,
+// a block owns one head row x 64 columns (lane = column), its waves split the batch.  Fixed-order LDS reduce (deterministic).
+__global__ __launch_bounds__(kHeadsThreads) void heads_wgrad_kernel(const float* __restrict__ cls, const float* __restrict__ dz,
                                                           const int32_t* __restrict__ head_row, int n_top, int B, int R, int H,
                                                           float* __restrict__ dWh, float* __restrict__ dbh, int accumulate,
+                                                          const uint32_t* __restrict__ mw, const int32_t* __restrict__ lay_row,
                                                           DropCfg drop) {
-  __shared__ float red[4][64];
-  __shared__ float redb[4];
-  const int r = blockIdx.x, h = blockIdx.y * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
-  const int lay = layer_of_row(r, head_row, n_top, nullptr);
+  __shared__ float red[kHeadsThreads / 64][64];
+  __shared__ float redb[kHeadsThreads / 64];
+  const int r = blockIdx.x, h = blockIdx.y * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lay = lay_row[r];
+  const int W = (H + 31) >> 5;
+  const uint32_t* mcol = mw + (int64_t)lay * B * W + (h >> 5);   // the layer's mask bits of column h: one word per sample
   float acc = 0.f, sb = 0.f;
   if (h < H) {
-#pragma unroll 4
-    for (int b = wave; b < B; b += 4) {
+#pragma unroll 16
+    for (int b = wave; b < B; b += nw) {
       const float g = dz[(int64_t)b * R + r];
       float xv = cls[(int64_t)b * H + h];
-      if (drop.thr16) xv = nb_keep(drop, (uint32_t)((lay * B + b) * H + h)) ? xv * drop.scale : 0.f;
+      if (drop.thr16) xv = ((mcol[(int64_t)b * W] >> (h & 31)) & 1u) ? xv * drop.scale : 0.f;
       acc = fmaf(g, xv, acc);
       sb += g;
     }
@@ -195,41 +245,50 @@ __global__ __launch_bounds__(256) void heads_wgrad_kernel(const float* __restric
   __syncthreads();
   if (wave == 0 && h < H) {
     const int l = threadIdx.x;
-    const float v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    float v = 0.f;
+    for (int w = 0; w < nw; ++w) v += red[w][l];
     float* o = dWh + (int64_t)r * H + h;
     *o = accumulate ? *o + v : v;
   }
   if (threadIdx.x == 0 && blockIdx.y == 0) {
-    const float v = (redb[0] + redb[1]) + (redb[2] + redb[3]);
+    float v = 0.f;
+    for (int w = 0; w < nw; ++w) v += redb[w];
     dbh[r] = accumulate ? dbh[r] + v : v;
   }
 }
 
 // dcls[b][h] = sum_r dz[b][r] * Wh[r][h] * dropmask_{layer(r)}(b,h).  grid (B, ceil(H/64)), block 256: waves split r
-__global__ __launch_bounds__(256) void heads_dgrad_kernel(const float* __restrict__ Wh, const float* __restrict__ dz,
+__global__ __launch_bounds__(kHeadsThreads) void heads_dgrad_kernel(const float* __restrict__ Wh, const float* __restrict__ dz,
                                                           const int32_t* __restrict__ head_row, int n_top, int R, int H,
-                                                          float* __restrict__ dcls, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // dz row [R] | layer of row [R] | red [4][64]
+                                                          float* __restrict__ dcls, const uint32_t* __restrict__ mw,
+                                                          const int32_t* __restrict__ lay_row, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // dz row [R] | layer of row [R] | red [waves][64]
   const int b = blockIdx.x, B = gridDim.x;
-  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y * 64 + l;
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y * 64 + l, nw = blockDim.x >> 6;
   float* red = sh + 2 * R;
   for (int r = threadIdx.x; r < R; r += blockDim.x) {
     sh[r] = dz[(int64_t)b * R + r];
-    sh[R + r] = (float)layer_of_row(r, head_row, n_top, nullptr);
+    sh[R + r] = (float)lay_row[r];
   }
   __syncthreads();
   float s = 0.f;
+  const int W = (H + 31) >> 5;
+  const uint32_t* mcol = mw + (int64_t)b * W + (h >> 5);       // this sample's mask bits of column h: one word per layer
   if (h < H) {
-#pragma unroll 4
-    for (int r = wave; r < R; r += 4) {
+#pragma unroll 16
+    for (int r = wave; r < R; r += nw) {
       float w = Wh[(int64_t)r * H + h];
-      if (drop.thr16) w = nb_keep(drop, (uint32_t)(((int)sh[R + r] * B + b) * H + h)) ? w * drop.scale : 0.f;
+      if (drop.thr16) w = ((mcol[(int64_t)(int)sh[R + r] * B * W] >> (h & 31)) & 1u) ? w * drop.scale : 0.f;
       s = fmaf(sh[r], w, s);
     }
   }
   red[wave * 64 + l] = s;
   __syncthreads();
-  if (wave == 0 && h < H) dcls[(int64_t)b * H + h] = (red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]);
+  if (wave == 0 && h < H) {
+    float v = 0.f;
+    for (int w = 0; w < nw; ++w) v += red[w * 64 + l];
+    dcls[(int64_t)b * H + h] = v;
+  }
 }
 
 template <typename T>
@@ -277,7 +336,8 @@ __global__ void decode_kernel(const float* __restrict__ top, const float* __rest
 }  // namespace
 
 extern "C" size_t nbest_heads_ws_bytes(int B, int R, int H) {
-  return ((size_t)B * H + (size_t)2 * B * R + (size_t)4 * B) * sizeof(float);
+  // cls | logits | dz | per-sample losses | dropout mask bits of at most R + 1 classifier layers
+  return ((size_t)B * H + (size_t)2 * B * R + (size_t)4 * B) * sizeof(float) + (size_t)(R + 1) * B * ((H + 31) / 32) * sizeof(uint32_t) + (size_t)R * sizeof(int32_t);
 }
 
 extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const float* Wh, const float* bh,
@@ -297,6 +357,8 @@ extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const flo
   float* logits = cls + (size_t)B * H;
   float* dz = logits + (size_t)B * R;
   float* sloss = dz + (size_t)B * R;
+  uint32_t* mw = (uint32_t*)(sloss + (size_t)4 * B);
+  int32_t* lay_row = (int32_t*)(mw + (size_t)(R + 1) * B * ((H + 31) / 32));
   const DropCfg d = make_drop(drop_p, seed, drop_stream);
   // number of softmax heads = R - n_top rows split over heads; the CE term averages over heads: count on host is not
   // available (device arrays), so it is passed implicitly: n_heads = #tops with head_row >= 0, computed by the caller
@@ -304,11 +366,12 @@ extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const flo
   // n_bottom = (R - n_top) + (n_top - n_heads)  =>  n_heads = R - n_bottom.
   const int n_heads = R - n_bottom;
   NB_CHECK(n_heads > 0, NBEST_ERR_SHAPE, "stc_heads: label space has no multi-value head");
-  const size_t smemH = (size_t)H * sizeof(float);
+  const int n_lay = n_heads + 1;
+  const size_t smemH = (size_t)H * sizeof(float) + (size_t)n_lay * ((H + 31) / 32) * sizeof(uint32_t) + (size_t)R * sizeof(int32_t);
   if (dtype == NBEST_F32)
-    heads_logits_kernel<float><<<dim3(B, kLogitSplit), 256, smemH, st>>>((const float*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, d);
+    heads_logits_kernel<float><<<dim3(B, kLogitSplit), kHeadsThreads, smemH, st>>>((const float*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, mw, lay_row, n_lay, d);
   else if (dtype == NBEST_BF16)
-    heads_logits_kernel<bf16><<<dim3(B, kLogitSplit), 256, smemH, st>>>((const bf16*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, d);
+    heads_logits_kernel<bf16><<<dim3(B, kLogitSplit), kHeadsThreads, smemH, st>>>((const bf16*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, mw, lay_row, n_lay, d);
   else NB_CHECK(false, NBEST_ERR_DTYPE, "stc_heads: bad dtype %d", dtype);
   NB_LAUNCH_CHECK();
   heads_scores_kernel<<<B, 64, 0, st>>>(logits, labels, ls->bottom_off, ls->bottom_ids, ls->head_row, n_top, n_bottom, R,
@@ -317,9 +380,9 @@ extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const flo
   loss_reduce_kernel<<<1, 256, 0, st>>>(sloss, B, loss_parts);
   NB_LAUNCH_CHECK();
   if (need_grad) {
-    heads_wgrad_kernel<<<dim3(R, (H + 63) / 64), 256, 0, st>>>(cls, dz, ls->head_row, n_top, B, R, H, dWh, dbh, accumulate, d);
+    heads_wgrad_kernel<<<dim3(R, (H + 63) / 64), kHeadsThreads, 0, st>>>(cls, dz, ls->head_row, n_top, B, R, H, dWh, dbh, accumulate, mw, lay_row, d);
     NB_LAUNCH_CHECK();
-    heads_dgrad_kernel<<<dim3(B, (H + 63) / 64), 256, ((size_t)2 * R + 256) * sizeof(float), st>>>(Wh, dz, ls->head_row, n_top, R, H, dcls, d);
+    heads_dgrad_kernel<<<dim3(B, (H + 63) / 64), kHeadsThreads, ((size_t)2 * R + kHeadsThreads) * sizeof(float), st>>>(Wh, dz, ls->head_row, n_top, R, H, dcls, mw, lay_row, d);
     NB_LAUNCH_CHECK();
   }
   return NBEST_OK;
