@@ -36,7 +36,7 @@ KERNELS = [
     ("quant_w8_kernel", None, "e4m3 weight copy (from the fp32 master)", None, 85e6 * 5 / 1e6),
     ("absmax_kernel", None, "per-matrix max |w| (weight scales)", None, 85e6 * 4 / 1e6),
     # ---- bf16 ----
-    ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 129024, "weight gradient FFN-up / FFN-down (3072x768 | 768x3072, K = 32 768)", gf(F, H, M), (M * (F + H) * 2 + F * H * 4) / 1e6),
+    ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 129024, "weight gradients, K = 32 768: FFN-down 768x3072 | FFN-up 3072x768 | QKV 2304x768 + attention-out 768x768 in one launch (round 3; 36 tiles x 7 K-splits each)", gf(F, H, M), (M * (F + H) * 2 + F * H * 4) / 1e6),
     ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 124416, "weight gradient QKV (2304x768)", gf(3 * H, H, M), (M * 4 * H * 2 + 3 * H * H * 4) / 1e6),
     ("gemm_bf16_kernel<true, true, 6>", None, "weight gradient attention-out (768x768)", gf(H, H, M), (M * 2 * H * 2 + H * H * 4) / 1e6),
     # round 3: register-epilogue kernels (256 x 256 tiles as 4 x 2 waves; 256 x 192 tiles for the N = 768 shapes)
