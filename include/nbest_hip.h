@@ -64,6 +64,19 @@ int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const int64_t* po
                        void* ws, size_t ws_bytes, nbest_stream_t stream);
 size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H);
 
+/* Sparse exchange of word-embedding gradient rows between data-parallel ranks (new functionality: the reference is single-process,
+ * /root/reference/n_best_asr_bert.py:232-294; the table is the nn.Embedding of the installed modeling_bert.py:154-177).  With a
+ * 250 002-row vocabulary only the rows of the tokens in a rank's shard are non-zero, so ranks exchange (row ids, row values):
+ *   nbest_rows_gather: slot i < n_rows of ids_out / vals_out takes table row rows[i] ([.][H] fp32, H % 4 == 0); slots n_rows .. cap-1
+ *                      are padding (id -1, zeros), so every rank sends the same `cap` slots;
+ *   nbest_rows_zero:   table[ids[i]][:] = 0;
+ *   nbest_rows_add:    table[ids[i]][:] += vals[i][:], ids unique within one call, negative ids skipped; no atomics - called once per
+ *                      rank's block in rank order, every replica performs the same additions in the same order.                    */
+int nbest_rows_gather(const float* table, const int64_t* rows, int64_t n_rows, int64_t cap, int64_t* ids_out, float* vals_out, int H,
+                      nbest_stream_t stream);
+int nbest_rows_zero(float* table, const int64_t* ids, int64_t n, int H, nbest_stream_t stream);
+int nbest_rows_add(float* table, const int64_t* ids, const float* vals, int64_t n, int H, nbest_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K2/K4/K6  dense GEMM on MFMA with fused epilogues
  * replaces nn.Linear inside BertSelfAttention / BertSelfOutput / BertIntermediate / BertOutput

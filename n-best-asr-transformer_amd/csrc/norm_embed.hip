@@ -604,6 +604,32 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict
     for (int64_t i = n8 << 3; i < n; ++i) dst[i] = (bf16)src[i];
 }
 
+// ---- sparse exchange of word-embedding gradient rows (data parallel, large vocabularies; trainer.GradReducer) ----------------
+// gather: slot i < n takes row rows[i] of the table (and its id), slots n .. cap-1 are padding (id -1, zeros)
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ rows, int64_t n,
+                                                          int64_t* __restrict__ ids_out, float* __restrict__ vals_out, int H) {
+  const int64_t i = blockIdx.x;
+  const int64_t id = (i < n) ? rows[i] : -1;
+  if (threadIdx.x == 0) ids_out[i] = id;
+  const int nvec = H >> 2;
+  for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
+    const f32x4 v = (id >= 0) ? *(const f32x4*)(table + id * H + 4 * c) : f32x4{0, 0, 0, 0};
+    *(f32x4*)(vals_out + i * H + 4 * c) = v;
+  }
+}
+// table[ids[i]] = 0 (vals == nullptr) or table[ids[i]] += vals[i]; ids unique within one call (negative ids are padding)
+__global__ __launch_bounds__(256) void rows_update_kernel(float* __restrict__ table, const int64_t* __restrict__ ids,
+                                                          const float* __restrict__ vals, int H) {
+  const int64_t i = blockIdx.x;
+  const int64_t id = ids[i];
+  if (id < 0) return;
+  const int nvec = H >> 2;
+  for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
+    float* p = table + id * H + 4 * c;
+    *(f32x4*)p = vals ? *(const f32x4*)p + *(const f32x4*)(vals + i * H + 4 * c) : f32x4{0, 0, 0, 0};
+  }
+}
+
 static inline int vpl_for(int H) { return ((H >> 2) + 63) / 64; }
 static inline int grid_rows(int64_t M, int wpb) {
   int64_t g = (M + wpb - 1) / wpb;
@@ -891,6 +917,32 @@ extern "C" int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const 
   } else NB_CHECK(false, NBEST_ERR_DTYPE, "embed_ln_bwd: bad dtype %d", dtype);
   NB_LAUNCH_CHECK();
   return finalize(part, nblk, H, dgamma, accumulate, dbeta, accumulate, nullptr, 0, st);
+}
+
+extern "C" int nbest_rows_gather(const float* table, const int64_t* rows, int64_t n_rows, int64_t cap, int64_t* ids_out,
+                                 float* vals_out, int H, nbest_stream_t stream) {
+  NB_CHECK(table && ids_out && vals_out && (rows || n_rows == 0) && n_rows >= 0 && cap >= n_rows && H > 0 && H % 4 == 0, NBEST_ERR_ARG,
+           "rows_gather: bad arguments");
+  if (cap == 0) return NBEST_OK;
+  rows_gather_kernel<<<(unsigned)cap, 256, 0, (hipStream_t)stream>>>(table, rows, n_rows, ids_out, vals_out, H);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_rows_zero(float* table, const int64_t* ids, int64_t n, int H, nbest_stream_t stream) {
+  NB_CHECK(table && (ids || n == 0) && n >= 0 && H > 0 && H % 4 == 0, NBEST_ERR_ARG, "rows_zero: bad arguments");
+  if (n == 0) return NBEST_OK;
+  rows_update_kernel<<<(unsigned)n, 256, 0, (hipStream_t)stream>>>(table, ids, nullptr, H);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+extern "C" int nbest_rows_add(float* table, const int64_t* ids, const float* vals, int64_t n, int H, nbest_stream_t stream) {
+  NB_CHECK(table && ((ids && vals) || n == 0) && n >= 0 && H > 0 && H % 4 == 0, NBEST_ERR_ARG, "rows_add: bad arguments");
+  if (n == 0) return NBEST_OK;
+  rows_update_kernel<<<(unsigned)n, 256, 0, (hipStream_t)stream>>>(table, ids, vals, H);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
 }
 
 extern "C" int nbest_cls_grad_scatter(const float* dcls, void* dhidden, int B, int S, int H, int dtype,

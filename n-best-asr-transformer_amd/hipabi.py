@@ -16,7 +16,7 @@ F32, BF16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_DGELU, EPI_RES, EPI_F32_SPLITK = range(7)
 
 EXPORTS = [
-    "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes",
+    "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes", "nbest_rows_gather", "nbest_rows_zero", "nbest_rows_add",
     "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_wgrad_pair_ws_bytes", "nbest_wgrad_pair", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
@@ -94,6 +94,9 @@ def lib():
                      "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes"):
             getattr(L, name).restype = C.c_size_t
         L.nbest_embed_bwd_ws_bytes.argtypes = [C.c_int64, C.c_int64]
+        L.nbest_rows_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.nbest_rows_zero.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.nbest_rows_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.nbest_rowred_ws_bytes.argtypes = [C.c_int64, C.c_int64]
         L.nbest_heads_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         L.nbest_gemm_ws_bytes.argtypes = [C.POINTER(GemmArgs)]
@@ -243,6 +246,24 @@ def wgrad_pair(dY1, X1, dY2, X2, out1=None, out2=None, accumulate=False):
     gs[0].ws, gs[0].ws_bytes = ws.data_ptr(), ws.numel()
     check(lib().nbest_wgrad_pair(C.byref(gs[0]), C.byref(gs[1]), stream_ptr()), "wgrad_pair")
     return outs
+
+
+def rows_gather(table, rows, cap):
+    """(ids [cap] int64 with -1 padding, vals [cap, H] fp32 with zero padding) <- rows of the fp32 table (nbest_rows_gather)"""
+    H = table.shape[1]
+    ids = torch.empty(cap, dtype=torch.long, device=table.device)
+    vals = torch.empty(cap, H, dtype=torch.float32, device=table.device)
+    check(lib().nbest_rows_gather(ptr(table), ptr(rows), rows.numel(), cap, ptr(ids), ptr(vals), H, stream_ptr()), "rows_gather")
+    return ids, vals
+
+
+def rows_zero(table, ids):
+    check(lib().nbest_rows_zero(ptr(table), ptr(ids), ids.numel(), table.shape[1], stream_ptr()), "rows_zero")
+
+
+def rows_add(table, ids, vals):
+    """table[ids[i]] += vals[i]; ids unique within the call, negative ids are padding"""
+    check(lib().nbest_rows_add(ptr(table), ptr(ids), ptr(vals), ids.numel(), table.shape[1], stream_ptr()), "rows_add")
 
 
 def gelu_d_decode(U):

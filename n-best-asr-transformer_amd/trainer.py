@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import hipabi as hb
 from .fscore import compute_f1, update_f1
 from .inputs import collate, encode_utterance, prepare_inputs_for_roberta
 
@@ -150,11 +151,14 @@ class GradReducer:
         lo, hi, shape = self.word
         G = self.arena.g[lo:hi].view(shape)
         dev = G.device
-        ids = torch.full((cap,), -1, dtype=torch.long, device=dev)
-        vals = torch.zeros(cap, shape[1], dtype=G.dtype, device=dev)
-        if rows.numel():
-            ids[:rows.numel()] = rows
-            vals[:rows.numel()] = G.index_select(0, rows)
+        if dev.type == "cuda":                                # library kernels (nbest_rows_gather): ids / values with padding in one launch
+            ids, vals = hb.rows_gather(G, rows, cap)
+        else:                                                 # gloo rehearsal on CPU tensors (tests/test_dp_gloo.py)
+            ids = torch.full((cap,), -1, dtype=torch.long, device=dev)
+            vals = torch.zeros(cap, shape[1], dtype=G.dtype, device=dev)
+            if rows.numel():
+                ids[:rows.numel()] = rows
+                vals[:rows.numel()] = G.index_select(0, rows)
         all_ids = torch.empty(self.world * cap, dtype=torch.long, device=dev)
         all_vals = torch.empty(self.world * cap, shape[1], dtype=G.dtype, device=dev)
         w1 = _all_gather_flat(all_ids, ids)
@@ -166,11 +170,13 @@ class GradReducer:
         w1, w2, rows, cnt, cap, all_ids, all_vals, G = self._sparse
         w1.wait()
         w2.wait()
+        on_gpu = G.device.type == "cuda"
         if rows.numel():
-            G.index_fill_(0, rows, 0.0)
+            hb.rows_zero(G, rows) if on_gpu else G.index_fill_(0, rows, 0.0)
         for r in range(self.world):                                     # the same additions in the same order on every rank
             if cnt[r]:
-                G.index_add_(0, all_ids[r * cap:r * cap + cnt[r]], all_vals[r * cap:r * cap + cnt[r]])
+                i, v = all_ids[r * cap:r * cap + cnt[r]], all_vals[r * cap:r * cap + cnt[r]]
+                hb.rows_add(G, i, v) if on_gpu else G.index_add_(0, i, v)      # ids unique within a rank's block: plain += , no atomics
         self._sparse = None
 
     # ---- dense buckets -------------------------------------------------------------------------------------------------

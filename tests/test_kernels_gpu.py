@@ -534,6 +534,28 @@ def test_wgrad_fp8_transposed_reads(M, N, K):
         close("wgrad_fp8 amax=%r -> scale 1" % bad, got3, ref, 1e-4)
 
 
+def test_sparse_row_exchange_kernels():
+    """nbest_rows_gather / _zero / _add (the word-embedding rows data-parallel ranks exchange, trainer.GradReducer) against the
+    torch index ops they replace: bit-exact (copies and one fp32 addition per element), padding slots (id -1, zeros) included."""
+    V, H, n, cap = 5000, 768, 37, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    table = torch.randn(V, H, generator=g).to(DEV)
+    rows = torch.randperm(V, generator=g)[:n].sort().values.to(DEV)
+    ids, vals = hb.rows_gather(table, rows, cap)
+    assert torch.equal(ids[:n], rows) and bool((ids[n:] == -1).all())
+    assert torch.equal(vals[:n], table.index_select(0, rows)) and bool((vals[n:] == 0).all())
+    ref = table.clone()
+    ref.index_fill_(0, rows, 0.0)
+    hb.rows_zero(table, rows)
+    assert torch.equal(table, ref)
+    other = torch.randn(cap, H, generator=g).to(DEV)
+    ref.index_add_(0, rows, other[:n])
+    hb.rows_add(table, ids, other)                      # the padding slots (id -1) must be skipped
+    assert torch.equal(table, ref)
+    e_ids, e_vals = hb.rows_gather(table, rows[:0], 1)  # a rank whose shard touches no row still sends one padding slot
+    assert e_ids.tolist() == [-1] and float(e_vals.abs().max()) == 0.0
+
+
 def test_transposed_weight_copies():
     """k-contiguous copies of the weight matrices for the dgrad GEMMs: bf16 transpose (nbest_transpose_weights) and e4m3 copy +
     its transpose (nbest_quantize_weights_fp8), on matrices that take the 16-byte tile path (dimensions multiples of 64) and on
