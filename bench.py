@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--no_dropout", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true", help="skip the in-step event timing (profiler passes)")
+    ap.add_argument("--no_packed_weights", action="store_true", help="A/B diagnostic: the GEMMs read the weight matrices row by row (round-2 behaviour)")
     a = ap.parse_args()
 
     rank, world, local = init_distributed()
@@ -203,6 +204,8 @@ def main():
     dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
     model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=dtype, dropout=0.0 if a.no_dropout else 0.3, seed=999,
                           fp8_forward=(a.dtype == "fp8w"))
+    if a.no_packed_weights:
+        model.arena.wpk = model.arena.wpkt = None
     model.load_reference_state(synth.model_state(cfg, labels, seed=999))     # random init of the named architecture
     broadcast_parameters(model)
     model.train()

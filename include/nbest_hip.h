@@ -121,6 +121,11 @@ typedef struct nbest_gemm_args {
   int32_t colsum_accumulate; /* colsum_out += instead of = */
   int32_t flags;             /* NBEST_GEMM_DEFER_REDUCE: F32_SPLITK leaves the per-split partial slabs in ws
                                 (layout [splits][M][N] fp32) and does NOT launch the reduce; C is untouched */
+  const void* B_packed;      /* optional (bf16, trans_a = trans_b = 0): the same matrix as B, pre-packed by nbest_pack_weights for tiles of
+                                b_pack_bn columns.  Used when the kernel chosen for this shape has that tile width (the LDS-DMA of the B
+                                tile becomes a linear copy); otherwise B is read.  Results are identical either way.               */
+  int32_t b_pack_bn;         /* 256 | 192 (nbest_pack_bn(N)), 0 = none */
+  int32_t pad_;
 } nbest_gemm_args;
 #define NBEST_GEMM_DEFER_REDUCE 1
 size_t nbest_gemm_ws_bytes(const nbest_gemm_args* a);
@@ -337,6 +342,15 @@ int nbest_quantize_weights_fp8(const float* master, void* w8, void* w8t, const n
                                int n_tiles, float* inv_scale, void* ws, size_t ws_bytes, nbest_stream_t stream);
 int nbest_transpose_weights(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_tiles,
                             nbest_stream_t stream);
+/* Weight matrices pre-packed for the k-contiguous GEMM kernels (nbest_gemm_args::B_packed).  For each matrix of `descs` (offset in
+ * elements into both arenas, rows = N, cols = K, pad = tile width nbest_pack_bn(N) > 0, cols % 32 == 0, rows % pad == 0; tile_start =
+ * running sum of (rows / pad) * (cols / 32) = index of the matrix' first (tile column, K stage) block; n_stages = that sum over all
+ * matrices) `dst` receives, for every tile column and every 32-deep K stage, the pad x 32 tile in the exact order the kernel's LDS image
+ * has (16-byte chunk swizzle and row permutation applied).  Same bytes as the source, N * K elements per matrix at the same offset.
+ * Once per optimizer step, beside nbest_transpose_weights / the bf16 copy refresh of nbest_bertadam_step (the nn.Linear weights of the
+ * installed modeling_bert.py:154-177, 282-293, 325-351 do not change inside a step).                                                   */
+int nbest_pack_bn(int64_t N);
+int nbest_pack_weights(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_stages, nbest_stream_t stream);
 /* fp32 -> bf16 copy of an arena (initial compute copy / after loading a checkpoint) */
 int nbest_cast_f32_to_bf16(const float* src, void* dst, int64_t n, nbest_stream_t stream);
 
@@ -384,6 +398,10 @@ typedef struct nbest_encoder_desc {
   uint32_t* gamax_new;
   int32_t fp8_bwd;
   int32_t pad2;
+  /* optional (bf16): the weight arena packed by nbest_pack_weights for the forward GEMMs (wpk: matrices as stored, [out][in]) and for
+   * the dgrad GEMMs (wpkt: packed from the TRANSPOSED copy wts_t), at the arena's element offsets; NULL = the GEMMs read wts / wts_t */
+  const void* wpk;
+  const void* wpkt;
 } nbest_encoder_desc;
 size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
 size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);

@@ -111,6 +111,8 @@ class ParamArena:
         self.w16t_stale = False
         self.w8 = self.w8t = self.w8_inv_scale = self._w8_ws = self.gamax = None
         self._tdescs = None
+        self.wpk = self.wpkt = None     # packed copies for the bf16 GEMMs (dropped when the fp8 mode is enabled: its GEMMs read w8 / w8t)
+        self._pdescs = None
         if self.w16 is not None and self.device.type == "cuda":
             self.w16t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
             H, F = cfg.hidden_size, cfg.intermediate_size
@@ -123,6 +125,25 @@ class ParamArena:
                 arr[i].offset, arr[i].rows, arr[i].cols, arr[i].tile_start = off, r, c, t
                 t += ((r + 63) // 64) * ((c + 63) // 64)
             self._tdescs = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(mats), t)
+            # the same matrices PACKED for the k-contiguous GEMM kernels (nbest_pack_weights): wpk from w16 ([out][in], forward GEMMs),
+            # wpkt from w16t ([in][out], dgrad GEMMs); a matrix whose shape has no packed form is left out of both tables (the GEMMs
+            # then read w16 / w16t - encoder.hip asks nbest_pack_bn the same question)
+            self.wpk = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+            self.wpkt = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+            self._pdescs = []
+            for transposed in (False, True):
+                sel = []
+                for off, r, c in mats:
+                    n, k = (c, r) if transposed else (r, c)
+                    bn = hb.lib().nbest_pack_bn(n)
+                    assert bn > 0 and k % 32 == 0 and n % bn == 0, "encoder matrix %d x %d has no packed form" % (n, k)
+                    sel.append((off, n, k, bn))
+                parr = (hb.MatrixDesc * len(sel))()
+                t = 0
+                for i, (off, n, k, bn) in enumerate(sel):
+                    parr[i].offset, parr[i].rows, parr[i].cols, parr[i].tile_start, parr[i].pad = off, n, k, t, bn
+                    t += (n // bn) * (k // 32)
+                self._pdescs.append((torch.frombuffer(bytearray(bytes(parr)), dtype=torch.uint8).to(self.device), len(sel), t))
         self._descs = None
 
     # ---- views ---------------------------------------------------------------------------------
@@ -167,12 +188,16 @@ class ParamArena:
         hb.check(hb.lib().nbest_transpose_weights(hb.ptr(self.w16), hb.ptr(self.w16t), hb.ptr(d), n, t, hb.stream_ptr()),
                  "transpose_weights")
         self.w16t_stale = False
+        if self.wpk is not None:
+            for src, dst, (pd, pn, pt) in ((self.w16, self.wpk, self._pdescs[0]), (self.w16t, self.wpkt, self._pdescs[1])):
+                hb.check(hb.lib().nbest_pack_weights(hb.ptr(src), hb.ptr(dst), hb.ptr(pd), pn, pt, hb.stream_ptr()), "pack_weights")
 
     def enable_fp8_forward(self):
         """allocate the e4m3 weight copy (one byte per element at the arena's element offsets) and its per-matrix inverse
         scales [4 L] (QKV, attention-out, FFN-up, FFN-down per layer) - BASELINE configs[4] "fp8 weights"."""
         if self.w16t is None:
             raise RuntimeError("nbest_amd: the fp8 forward needs the bf16 path on a GPU")
+        self.wpk = self.wpkt = None          # the fp8 GEMMs read w8 / w8t; the bf16 fall-back GEMMs read w16 / w16t unpacked
         if self.w8 is None:
             n = self._tdescs[1]
             self.w8 = torch.zeros(self.total, dtype=torch.uint8, device=self.device)

@@ -184,8 +184,9 @@ struct Ptrs {
 static int gemm(int dtype, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                 int64_t ldc, int ta, int tb, int epi, const float* bias, const void* R, int64_t ldr, void* U, int64_t ldu,
                 void* ws, size_t ws_bytes, int accumulate, float drop_p, uint64_t seed, uint32_t stream_id, hipStream_t st,
-                float* colsum_out = nullptr) {
+                float* colsum_out = nullptr, const void* B_packed = nullptr) {
   nbest_gemm_args g = {};
+  if (B_packed && !ta && !tb) { g.B_packed = B_packed; g.b_pack_bn = nbest_pack_bn(N); }
   g.colsum_out = colsum_out; g.colsum_accumulate = accumulate;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.R = R; g.U = U; g.ws = ws; g.ws_bytes = ws_bytes;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.ldu = ldu;
@@ -224,6 +225,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
   const int64_t M = a.M;
   const int H = d->H, F = d->F, dt = d->dtype;
   const size_t MH = al((size_t)M * H * a.esz);
+  auto PK = [&](int64_t off) -> const void* { return (d->wpk && dt == NBEST_BF16) ? (const void*)((const char*)d->wpk + off * 2) : nullptr; };
   auto X = [&](int l) { return (void*)(A + a.X + (size_t)l * MH); };
   const uint32_t sb = d->drop_stream_base;
 
@@ -255,7 +257,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
       RUN(gemm8(x8, o.wqkv, 4 * l + 0, qkv, 3 * H, H, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, nullptr, nullptr, 0.f, 0));
     } else
     RUN(gemm(dt, X(l), P.W(o.wqkv), qkv, M, 3 * H, H, H, H, 3 * H, 0, 0, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, 0, nullptr, 0,
-             nullptr, 0, 0, 0.f, 0, 0, st));
+             nullptr, 0, 0, 0.f, 0, 0, st, nullptr, PK(o.wqkv)));
     uint32_t* keepw = (a.keep_bytes && d->attn_drop > 0.f) ? (uint32_t*)(Lb + a.o_keep) : nullptr;
     RUN(nbest_internal_attention_fwd8(qkv, key_mask, ctx, ctx8, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream, keepw));
     // attention output projection + dropout + residual, then LayerNorm
@@ -263,7 +265,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
       RUN(gemm8(ctx8, o.wo, 4 * l + 1, r1, H, H, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), nullptr, nullptr, d->hidden_drop, s0 + 1));
     } else
     RUN(gemm(dt, ctx, P.W(o.wo), r1, M, H, H, H, H, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), H, nullptr, 0, nullptr, 0, 0,
-             d->hidden_drop, d->seed, s0 + 1, st));
+             d->hidden_drop, d->seed, s0 + 1, st, nullptr, PK(o.wo)));
     RUN(nbest_internal_layernorm_fwd8(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, x18, st1, M, H, d->ln_eps, dt, stream));
     // FFN up + bias + GELU (GELU' of the pre-activation kept for the backward)
     if (f8) {
@@ -271,13 +273,13 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
       RUN(gemm8(x18, o.w1, 4 * l + 2, fp8_backward_active(d) ? nullptr : hact, F, H, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, u, h8, 0.f, 0));
     } else
     RUN(gemm(dt, x1, P.W(o.w1), hact, M, F, H, H, H, F, 0, 0, NBEST_EPI_BIAS_GELU, P.P(o.b1), nullptr, 0, u, F, nullptr, 0, 0, 0.f,
-             0, 0, st));
+             0, 0, st, nullptr, PK(o.w1)));
     // FFN down + dropout + residual, then LayerNorm
     if (f8) {
       RUN(gemm8(h8, o.w2, 4 * l + 3, r2, H, F, NBEST_EPI_BIAS_DROP_RES, P.P(o.b2), x1, nullptr, nullptr, d->hidden_drop, s0 + 2));
     } else
     RUN(gemm(dt, hact, P.W(o.w2), r2, M, H, F, F, F, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.b2), x1, H, nullptr, 0, nullptr, 0, 0,
-             d->hidden_drop, d->seed, s0 + 2, st));
+             d->hidden_drop, d->seed, s0 + 2, st, nullptr, PK(o.w2)));
     RUN(nbest_internal_layernorm_fwd8(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), x8_next, st2, M, H, d->ln_eps, dt, stream));
   }
   if (hidden_out) *hidden_out = X(d->L);
@@ -301,6 +303,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   const bool wt = (wts_t != nullptr);
   const Ptrs PT{(const char*)(wt ? wts_t : wts), prm, a.esz};
   const int tbd = wt ? 0 : 1;
+  auto PKT = [&](int64_t off) -> const void* { return (wt && d->wpkt && d->dtype == NBEST_BF16) ? (const void*)((const char*)d->wpkt + off * 2) : nullptr; };
   char* A = (char*)act;
   char* W = (char*)ws;
   const int64_t M = a.M;
@@ -367,7 +370,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
       RUN(dgrad8(dRd8, 4 * l + 0, o.w2, 4 * l + 3, nullptr, F, H, NBEST_EPI_DGELU, nullptr, u, dBig8, 4 * l + 1, G(o.b1)));
     } else {
       RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red1, w.red_bytes, accumulate,
-               0.f, 0, 0, st, G(o.b1)));
+               0.f, 0, 0, st, G(o.b1), PKT(o.w2)));
       if (rec) RUN(nbest_internal_amax_bf16(dBig, M * F, d->gamax_new + 4 * l + 1, st));   // calibration pass: this producer is a bf16 kernel
     }
     stamp(0);
@@ -377,7 +380,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     stamp(1);
     // FFN-up: dgrad + residual gradient ; wgrad
     if (f8b) RUN(dgrad8(dBig8, 4 * l + 1, o.w1, 4 * l + 2, dB1, H, F, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
-    else RUN(gemm(dt, dBig, PT.W(o.w1), dB1, M, H, F, F, wt ? F : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    else RUN(gemm(dt, dBig, PT.W(o.w1), dB1, M, H, F, F, wt ? F : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st, nullptr, PKT(o.w1)));
     stamp(0);
     if (f8b) RUN(nbest_wgrad_fp8(dBig8, x18, G(o.w1), F, H, M, F, H, H, d->gamax_prev + 4 * l + 1, accumulate, slab, w.slab_bytes, stream));
     else RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
@@ -388,7 +391,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
                                       accumulate, d->hidden_drop, d->seed, s0 + 1, red2, w.red_bytes, stream, fg(dRd8, 4 * l + 2)));
     // attention output projection: dgrad ; wgrad
     if (f8b) RUN(dgrad8(dRd8, 4 * l + 2, o.wo, 4 * l + 1, dctx, H, H, NBEST_EPI_NONE, nullptr, nullptr, nullptr, -1, nullptr));
-    else RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    else RUN(gemm(dt, dRd, PT.W(o.wo), dctx, M, H, H, H, H, H, 0, tbd, NBEST_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st, nullptr, PKT(o.wo)));
     // (bf16: this layer's dRd and ctx stay untouched until the next layer's LayerNorm backward - the gradient is issued below, with QKV's)
     if (!paired) {
       stamp(0);
@@ -403,7 +406,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
                                       (a.keep_bytes && d->attn_drop > 0.f) ? (const uint32_t*)(Lb + a.o_keep) : nullptr));
     // QKV projection: dgrad + residual gradient -> gradient wrt the layer input ; wgrad
     if (f8b) RUN(dgrad8(dqkv8, 4 * l + 3, o.wqkv, 4 * l + 0, dA, H, 3 * H, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
-    else RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st));
+    else RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st, nullptr, PKT(o.wqkv)));
     stamp(0);
     if (f8b) RUN(nbest_wgrad_fp8(dqkv8, x8, G(o.wqkv), 3 * H, H, M, 3 * H, H, H, d->gamax_prev + 4 * l + 3, accumulate, slab, w.slab_bytes, stream));
     else if (paired) {

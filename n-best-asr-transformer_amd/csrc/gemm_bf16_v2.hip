@@ -52,6 +52,10 @@ struct GemmP2 {
   const bf16* A2; const bf16* B2;
   int64_t lda2, ldb2, m_split;
   uint32_t a2_bytes, b2_bytes;
+  // B pre-packed for this kernel's tile (nbest_pack_weights): the LDS image of every (tile column, K stage) stored contiguously;
+  // nullptr: B is read row by row
+  const bf16* Bp;
+  uint32_t bp_bytes;
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
@@ -90,6 +94,26 @@ __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* til
     char* dst = tile + (i * NT + wave * 64) * 16;
     if constexpr ((ROWS * 4) % NT != 0) {
       if (i == NI - 1 && (i * NT + wave * 64) * 16 >= ROWS * 64) {   // wave-uniform: this wave has no chunk in the last instruction
+        voff = 0xFFFFFFF0u;
+        dst = dump + (wave % (NT / 64)) * 1024;
+      }
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, 0, 0, AUX);
+  }
+}
+
+// the same tile from a PRE-PACKED operand: the LDS image of every (tile, stage) stored contiguously, so the LDS-DMA is a linear copy
+// (1 KiB contiguous per wave-instruction instead of sixteen 64-byte row segments)
+template <int ROWS, int NT, int AUX = 0>
+__device__ __forceinline__ void stage_tile_packed(__amdgpu_buffer_rsrc_t rs, char* tile, uint32_t stage_byte0, int tid, char* dump = nullptr) {
+  const int wave = tid >> 6;
+  constexpr int NI = (ROWS * 4 + NT - 1) / NT;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    uint32_t voff = stage_byte0 + (uint32_t)(i * NT + tid) * 16u;
+    char* dst = tile + (i * NT + wave * 64) * 16;
+    if constexpr ((ROWS * 4) % NT != 0) {
+      if (i == NI - 1 && (i * NT + wave * 64) * 16 >= ROWS * 64) {
         voff = 0xFFFFFFF0u;
         dst = dump + (wave % (NT / 64)) * 1024;
       }
@@ -151,7 +175,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   if ((DIAG & 32) && p.U && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 700))                       \
     ((uint64_t*)p.U)[16000 + (blockIdx.x ? 8 : 0) + (IDX)] = __builtin_readcyclecounter()
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB, int EPI>
+template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB, int EPI, bool SYM = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   NB_STAMP(0);
@@ -190,7 +214,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)opB, 0, b_bytes, 0x00020000);
+  const bool b_packed = kDirect && NT == 512 && p.Bp != nullptr;      // workgroup-uniform
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(b_packed ? (void*)p.Bp : (void*)opB, 0, b_packed ? p.bp_bytes : b_bytes, 0x00020000);
+  const int nkt = (int)(p.K / BK);
 
   // epilogue operands that do not depend on the K loop
   constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES);
@@ -221,7 +247,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
   const int dg = lane >> 4, dc = lane & 15;
   const int64_t dcol = n0 + wn * WTN + TNt * dc;
   const int64_t drow0 = m0 + wm * WTM + 4 * dg;
-  constexpr int NPRE0 = 1;   // 16-row tiles whose residual / GELU' rows are fetched before the K loop (the rest right after it)
+  constexpr int NPRE0 = SYM ? 0 : 1;   // 16-row tiles whose residual / GELU' rows are fetched before the K loop (the rest right after it)
   float db[TNt];
   u32x4 dpre[TMt][4];        // TNt = 8: 16 bytes of residual (8 bf16) per (i, e); TNt = 6: 12 bytes; TNt = 4: 8 bytes; GELU': TNt bytes
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.c_bytes, 0x00020000);
@@ -243,7 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       }
     }
   };
-  if constexpr (kDirect) {
+  auto load_bias = [&]() {
     if (kHasBias) {
 #pragma unroll
       for (int q = 0; q < TNt / 2; ++q) {
@@ -251,6 +277,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         db[2 * q] = b2[0]; db[2 * q + 1] = b2[1];
       }
     }
+  };
+  if constexpr (kDirect) {
+    if constexpr (!SYM) load_bias();
     if (kHasR || kHasUin) {
 #pragma unroll
       for (int i = 0; i < NPRE0; ++i) load_dpre(i);
@@ -263,7 +292,99 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
     for (int j = 0; j < TNt; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  if constexpr (NT == 512) {
+  if constexpr (SYM) {
+    // ---- symmetric software pipeline (experiment): every wave interleaves the fragment reads of stage kt+1 (second register set)
+    // with the MFMAs of stage kt; ONE workgroup barrier per stage (stage kt+1 landed for everyone / slot of stage kt-1 free).
+    static_assert(NT == 512 && kDirect && !TA && !TB, "SYM: k-contiguous 8-wave tiles only");
+    // The current stage lives in registers only: after the barrier of stage kt every wave has its fragments of stage kt (lgkmcnt(0)
+    // before the barrier), so slot kt % STAGES is refilled with stage kt + STAGES right away - three stages stay in flight.
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES; ++s0) {
+      if (s0 < nk) {
+        stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0a, kbeg + (int64_t)s0 * BK, lda_, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, ldb_, tid, lds + STAGES * STAGE);
+      }
+    }
+    {
+      const int younger = (nk - 1 < STAGES - 1) ? nk - 1 : STAGES - 1;
+      if (younger >= 3) wait_vm<3 * NDMA>();
+      else if (younger == 2) wait_vm<2 * NDMA>();
+      else if (younger == 1) wait_vm<NDMA>();
+      else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 aP[TMt], bP[TNt], aQ[TMt], bQ[TNt];
+#pragma unroll
+    for (int j = 0; j < TNt; ++j) bP[j] = read_frag2<false, BN>(lds + A_BYTES, wn * WTN + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < TMt; ++i) aP[i] = read_frag2<false, BM>(lds, wm * WTM + i * 16, lane);
+    int buf = 0;
+    // body of a stage that has a successor: wait for / publish stage kt+1, refill the ring, then ONE basic block of 32 MFMAs on the
+    // current fragments with the 12 reads of the next fragments spread between them
+    auto body = [&](int kt, bf16x8 (&aX)[TMt], bf16x8 (&bX)[TNt], bf16x8 (&aY)[TMt], bf16x8 (&bY)[TNt]) {
+      // issued so far: stages .. kt+3 (those below nk); stage kt+1 must have landed, this wave's fragments of stage kt too
+      if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory");
+      else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + STAGES < nk && !(DIAG & 256)) {
+        const int64_t k0 = kbeg + (int64_t)(kt + STAGES) * BK;
+        stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + buf * STAGE, m0a, k0, lda_, tid);
+        stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + buf * STAGE + A_BYTES, n0, k0, ldb_, tid, lds + STAGES * STAGE);
+      }
+      int nx = buf + 1;
+      if (nx >= STAGES) nx -= STAGES;
+      const char* nxt = lds + nx * STAGE;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(DIAG & 128)) {
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) bY[j] = read_frag2<false, BN>(nxt + A_BYTES, wn * WTN + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < TMt; ++i) aY[i] = read_frag2<false, BM>(nxt, wm * WTM + i * 16, lane);
+      } else {
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) bY[j] = bX[j];
+#pragma unroll
+        for (int i = 0; i < TMt; ++i) aY[i] = aX[i];
+      }
+      if constexpr (!(DIAG & 64)) {
+#pragma unroll
+      for (int i = 0; i < TMt; ++i)
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aX[i], bX[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TMt; ++i) asm volatile("" :: "v"(aX[i]));
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) asm volatile("" :: "v"(bX[j]));
+      }
+      if constexpr (!(DIAG & (64 | 128 | 512))) {
+      constexpr int N3 = TMt * TNt - 2 * (TMt + TNt), N2 = TMt + TNt - N3;
+      static_assert(N3 >= 0 && N2 >= 0, "SYM: interleave pattern");
+#pragma unroll
+      for (int g = 0; g < N3; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < N2; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      buf = nx;
+    };
+    // (the body of the LAST stage runs the same code: its barrier is harmless and its fragment reads fetch a stale slot nobody uses -
+    // a separate tail would be a third copy of the body, and the register allocator spilled 300 dwords per thread around it)
+    for (int kt = 0; kt < nk; kt += 2) {
+      body(kt, aP, bP, aQ, bQ);
+      if (kt + 1 < nk) body(kt + 1, aQ, bQ, aP, bP);
+    }
+    load_bias();
+  } else if constexpr (NT == 512) {
     // ---- ping-pong (8 waves = 2 groups of one wave per SIMD): a group alternates a LOAD slot (fragment
     // reads of stage j, LDS-DMA of stage j+STAGES-1, counted vmcnt) with an MFMA slot (stage j); group 1
     // runs one slot behind group 0, so on every SIMD one wave is always in its MFMA slot while the other
@@ -273,6 +394,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
         stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0a, kbeg + (int64_t)s0 * BK, lda_, tid);
+        if (b_packed) stage_tile_packed<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, (uint32_t)((tile_n * nkt + s0) * B_BYTES), tid, lds + STAGES * STAGE);
+        else
         stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK, ldb_, tid, lds + STAGES * STAGE);
       }
     }
@@ -295,6 +418,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK;
         stage_tile2<TA, BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0a, k0, lda_, tid);
+        if (b_packed) stage_tile_packed<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, (uint32_t)((tile_n * nkt + kt + STAGES - 1) * B_BYTES), tid, lds + STAGES * STAGE);
+        else
         stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, ldb_, tid, lds + STAGES * STAGE);
       }
       const char* cur = lds + buf * STAGE;
@@ -853,6 +978,31 @@ __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float* __rest
   }
 }
 
+// B operand (a weight matrix [N][K], k-contiguous) -> the order the 256 x bn ping-pong kernel stages it: for every tile column and
+// K stage the bn x 32 LDS image (chunk swizzle and the register epilogue's row permutation applied), contiguous.  LDS-DMA with
+// 64-byte row segments delivers 22 B/clk/CU, contiguous 47 (tools/micro/dma_rate.hip); with MFMAs removed the k-contiguous GEMMs
+// still take 75-85 % of their time (DMA + barriers), so the B half of the staging traffic is worth packing once per optimizer step.
+__global__ __launch_bounds__(256) void pack_b_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                     const nbest_matrix_desc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const nbest_matrix_desc d = descs[lo];
+  const int bn = d.pad, pw = (bn == 256) ? 128 : 96;            // wave-tile width of the kernel that reads it (kPW)
+  const int nk = d.cols / BK, t = blockIdx.x - d.tile_start, tile_n = t / nk, kt = t - tile_n * nk;
+  const bf16* s = src + d.offset + ((int64_t)tile_n * bn) * d.cols + (int64_t)kt * BK;
+  bf16* o = dst + d.offset + ((int64_t)tile_n * nk + kt) * bn * BK;
+  for (int p = threadIdx.x; p < bn * 4; p += blockDim.x) {
+    const int row = p >> 2, slot = p & 3;
+    const int kc = slot ^ ((-(row >> 2)) & 3);                   // stage_tile2<false>: the chunk swizzle
+    const int x = row % pw;
+    const int grow = row - x + (pw / 16) * (x & 15) + (x >> 4);  // and its PW row permutation
+    *(i32x4*)(o + (int64_t)p * 8) = *(const i32x4*)(s + (int64_t)grow * d.cols + kc * 8);
+  }
+}
+
 struct Plan {
   int bm, bn, splits;
   int64_t kps;
@@ -864,6 +1014,10 @@ struct Plan {
 #ifdef NBEST_EXPERIMENTS
 static bool persistent_enabled() {
   static const bool v = [] { const char* e = getenv("NBEST_PERSISTENT"); return e && *e == '1'; }();
+  return v;
+}
+static bool sym_enabled() {
+  static const bool v = [] { const char* e = getenv("NBEST_SYM"); return e && *e == '1'; }();
   return v;
 }
 static int forced_tile() {
@@ -881,6 +1035,7 @@ static int forced_tile() {
 }
 #else
 static constexpr bool persistent_enabled() { return false; }
+static constexpr bool sym_enabled() { return false; }
 static constexpr int forced_tile() { return 0; }
 #endif
 
@@ -941,14 +1096,14 @@ static Plan make_plan(const nbest_gemm_args* a) {
   return pl;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB>
+template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB, bool SYM = false>
 static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
   constexpr int lds_bytes = STAGES * (BM + BN) * BK * 2 + (((BN * 4) % NT) ? (NT / 64) * 1024 : 0);   // + the zero-fill dump slots
 #define L(E)                                                                                                        \
   case E:                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-    gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E><<<grid, NT, lds_bytes, st>>>(p);                                 \
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E, SYM><<<grid, NT, lds_bytes, st>>>(p);                            \
     break;
   if constexpr (BN / WN == 64) {   // the fp32 split-K output goes through the LDS-restaged epilogue (64-column wave tiles)
     if (epi == NBEST_EPI_F32_SPLITK) {
@@ -1018,6 +1173,12 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
   p.slab = (float*)a->ws;
   p.colpart = nullptr;
   p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.m_split = 0; p.a2_bytes = p.b2_bytes = 0;
+  p.Bp = nullptr; p.bp_bytes = 0;
+  if (a->B_packed && a->b_pack_bn == pl.bn && pl.bm == 256 && (pl.bn == 256 || pl.bn == 192) && !a->trans_a && !a->trans_b &&
+      a->epilogue != NBEST_EPI_F32_SPLITK && a->K % BK == 0 && a->N * a->K * 2 < ((int64_t)1 << 32) && ((uintptr_t)a->B_packed & 15) == 0) {
+    p.Bp = (const bf16*)a->B_packed;
+    p.bp_bytes = (uint32_t)(a->N * a->K * 2);
+  }
   if (a->colsum_out && a->epilogue != NBEST_EPI_F32_SPLITK) {
     NB_CHECK(a->ws && a->ws_bytes >= nbest_gemm_bf16_v2_ws_bytes(a), NBEST_ERR_WORKSPACE, "gemm: column-sum workspace too small");
     p.colpart = (float*)a->ws;
@@ -1090,7 +1251,14 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
 #endif
   } else if (pl.bm == 256 && pl.bn == 256) {
     // k-contiguous operands: 4 x 2 waves with 64 x 128 wave tiles (register epilogue: 16-byte stores, whole 128-byte lines)
-    if (!a->trans_a && !a->trans_b && epi != NBEST_EPI_F32_SPLITK) { rc = launch2<256, 256, 4, 2, 4, false, false>(p, epi, grid, st); wave_rows = 4; }
+    if (!a->trans_a && !a->trans_b && epi != NBEST_EPI_F32_SPLITK) {
+#ifdef NBEST_EXPERIMENTS
+      if (sym_enabled()) rc = launch2<256, 256, 4, 2, 4, false, false, true>(p, epi, grid, st);
+      else
+#endif
+      rc = launch2<256, 256, 4, 2, 4, false, false>(p, epi, grid, st);
+      wave_rows = 4;
+    }
     else if (!a->trans_a && !a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, true>(p, epi, grid, st);
     else rc = launch2<256, 256, 2, 4, 4, true, true>(p, epi, grid, st);
@@ -1144,4 +1312,18 @@ int nbest_wgrad_pair_bf16(const nbest_gemm_args* a, const nbest_gemm_args* b, hi
   NB_CHECK(b->lda % 8 == 0 && b->ldb % 8 == 0 && b->ldc % 8 == 0 && ((uintptr_t)b->A & 15) == 0 && ((uintptr_t)b->B & 15) == 0 &&
                ((uintptr_t)b->C & 15) == 0, NBEST_ERR_ALIGN, "wgrad pair: second problem misaligned");
   return gemm_v2_impl(&v, b, a->M, st);
+}
+
+// tile width the k-contiguous GEMM of an [N][K] weight matrix is packed for (0: not packed): the rule of make_plan at training-size
+// token counts - 256-column tiles for the wide matrices, 192-column tiles for N = 768-like shapes
+int nbest_pack_bn_internal(int64_t N) {
+  if (N % 256 == 0 && N >= 1024) return 256;
+  if (N % 192 == 0) return 192;
+  return 0;
+}
+
+int nbest_pack_weights_bf16(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_stages, hipStream_t st) {
+  pack_b_kernel<<<n_stages, 256, 0, st>>>((const bf16*)src, (bf16*)dst, descs, n_matrices);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
 }

@@ -167,6 +167,16 @@ extern "C" int nbest_gemm(const nbest_gemm_args* a, nbest_stream_t stream) {
   return NBEST_ERR_DTYPE;
 }
 
+// ---- pre-packed weight matrices (include/nbest_hip.h) ------------------------------------------------------------------
+int nbest_pack_bn_internal(int64_t N);
+int nbest_pack_weights_bf16(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_stages, hipStream_t st);
+extern "C" int nbest_pack_bn(int64_t N) { return nbest_pack_bn_internal(N); }
+extern "C" int nbest_pack_weights(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_stages,
+                                  nbest_stream_t stream) {
+  NB_CHECK(src && dst && descs && n_matrices > 0 && n_stages > 0 && src != dst, NBEST_ERR_ARG, "pack_weights: bad arguments");
+  return nbest_pack_weights_bf16(src, dst, descs, n_matrices, n_stages, (hipStream_t)stream);
+}
+
 // ---- two weight gradients, one launch (include/nbest_hip.h) ------------------------------------------------------------
 size_t nbest_wgrad_pair_bf16_ws_bytes(const nbest_gemm_args* a, const nbest_gemm_args* b);
 int nbest_wgrad_pair_bf16(const nbest_gemm_args* a, const nbest_gemm_args* b, hipStream_t st);

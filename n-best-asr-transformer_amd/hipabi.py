@@ -17,7 +17,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_DGELU, EPI_RES, EPI_F3
 
 EXPORTS = [
     "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes", "nbest_rows_gather", "nbest_rows_zero", "nbest_rows_add",
-    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_wgrad_pair_ws_bytes", "nbest_wgrad_pair", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
+    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_wgrad_pair_ws_bytes", "nbest_wgrad_pair", "nbest_pack_bn", "nbest_pack_weights", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_wgrad_launches_per_layer", "nbest_encoder_forward",
@@ -32,7 +32,8 @@ class GemmArgs(C.Structure):
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64), ("ldu", C.c_int64),
                 ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("dtype", C.c_int32),
                 ("accumulate", C.c_int32), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64),
-                ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("flags", C.c_int32)]
+                ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("flags", C.c_int32),
+                ("B_packed", C.c_void_p), ("b_pack_bn", C.c_int32), ("pad_", C.c_int32)]
 
 
 class GemmFp8Args(C.Structure):
@@ -72,7 +73,8 @@ class EncoderDesc(C.Structure):
                 ("layers_host", C.POINTER(LayerOffsets)), ("seed", C.c_uint64), ("drop_stream_base", C.c_uint32),
                 ("wgrad_events_n", C.c_int32), ("wgrad_events", C.POINTER(C.c_void_p)),
                 ("w8", C.c_void_p), ("w8_inv_scale", C.c_void_p), ("w8t", C.c_void_p), ("gamax_prev", C.c_void_p),
-                ("gamax_new", C.c_void_p), ("fp8_bwd", C.c_int32), ("pad2", C.c_int32)]
+                ("gamax_new", C.c_void_p), ("fp8_bwd", C.c_int32), ("pad2", C.c_int32),
+                ("wpk", C.c_void_p), ("wpkt", C.c_void_p)]
 
 
 _lib = None
@@ -129,6 +131,8 @@ def lib():
         L.nbest_encoder_forward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 7 + [sz, vp, sz, C.POINTER(C.c_void_p), vp]
         L.nbest_encoder_backward.argtypes = [C.POINTER(EncoderDesc)] + [vp] * 9 + [sz, vp, vp, sz, i32, i32, i32, i32, vp]
         L.nbest_transpose_weights.argtypes = [vp, vp, vp, i32, i32, vp]
+        L.nbest_pack_bn.argtypes = [i64]
+        L.nbest_pack_weights.argtypes = [vp, vp, vp, i32, i32, vp]
         L.nbest_gemm_fp8.argtypes = [C.POINTER(GemmFp8Args), vp]
         L.nbest_cast_bf16_to_fp8.argtypes = [vp, vp, i64, vp]
         L.nbest_wgrad_fp8_ws_bytes.restype = C.c_size_t
@@ -196,8 +200,22 @@ def gemm_prepared(A, B, M, N, K, out, trans_a=False, trans_b=False, epilogue=EPI
     return launch
 
 
+def pack_weight(W):
+    """W [N, K] bf16 (k-contiguous) -> (packed copy, tile width) for nbest_gemm_args::B_packed, or (None, 0) when the shape has no packed form"""
+    N, K = W.shape
+    bn = lib().nbest_pack_bn(N)
+    if bn == 0 or K % 32 or N % bn:
+        return None, 0
+    d = (MatrixDesc * 1)()
+    d[0].offset, d[0].rows, d[0].cols, d[0].tile_start, d[0].pad = 0, N, K, 0, bn
+    dd = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(W.device)
+    out = torch.empty_like(W)
+    check(lib().nbest_pack_weights(ptr(W), ptr(out), ptr(dd), 1, (N // bn) * (K // 32), stream_ptr()), "pack_weights")
+    return out, bn
+
+
 def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=None, R=None, U=None, out=None,
-         accumulate=False, drop_p=0.0, seed=0, drop_stream=0, colsum_out=None, defer_reduce=False):
+         accumulate=False, drop_p=0.0, seed=0, drop_stream=0, colsum_out=None, defer_reduce=False, B_packed=None, b_pack_bn=0):
     """C[M,N] = epi(op(A) . op(B)); returns C (and U for EPI_BIAS_GELU)."""
     dt = dtype_code(A.dtype)
     dev = A.device
@@ -218,6 +236,8 @@ def gemm(A, B, M, N, K, trans_a=False, trans_b=False, epilogue=EPI_NONE, bias=No
     g.accumulate, g.drop_p, g.drop_stream, g.seed = int(accumulate), drop_p, drop_stream, seed
     g.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
     g.flags = 1 if defer_reduce else 0
+    if B_packed is not None:
+        g.B_packed, g.b_pack_bn = B_packed.data_ptr(), b_pack_bn
     nb = lib().nbest_gemm_ws_bytes(C.byref(g))
     ws = _ws(nb, dev)
     g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()

@@ -223,6 +223,7 @@ class NBestSTCModel(nn.Module):
         d.seed = self._step_seed()
         if self.fp8_forward:
             d.w8, d.w8_inv_scale = self.arena.w8.data_ptr(), self.arena.w8_inv_scale.data_ptr()
+        self._set_packed(d)
         self._set_fp8_backward(d)    # the forward leaves out the bf16 tensors an fp8 backward will not read
         out = C.c_void_p()
         hb.check(hb.lib().nbest_encoder_forward(C.byref(d), hb.ptr(self.arena.weights), hb.ptr(self.arena.p), hb.ptr(ids),
@@ -235,6 +236,13 @@ class NBestSTCModel(nn.Module):
         esz = 2 if self.compute_dtype == torch.bfloat16 else 4
         ps.hidden = ps.act[off:off + M * H * esz].view(self.compute_dtype).view(M, H)
         return ps.hidden
+
+    def _set_packed(self, d):
+        """packed weight copies (arena.wpk / wpkt, refreshed with the transposed copy after every optimizer step)"""
+        a = self.arena
+        ok = getattr(a, "wpk", None) is not None and not a.w16t_stale
+        d.wpk = a.wpk.data_ptr() if ok else None
+        d.wpkt = a.wpkt.data_ptr() if ok else None
 
     def _set_fp8_backward(self, d):
         """descriptor fields of the fp8 backward; the same values in the forward and the backward of one step"""
@@ -250,6 +258,7 @@ class NBestSTCModel(nn.Module):
         self._set_fp8_backward(ps.desc)
         if self.arena.w16t_stale and not (self.fp8_backward and self._gamax_valid):
             self.arena.refresh_w16t()             # a bf16 backward after fp8 steps (history dropped, mode switched)
+        self._set_packed(ps.desc)
         dh = hb.cls_grad_scatter(dcls, ps.B, ps.S, cfg.hidden_size, self.compute_dtype)
         ids, seg, pos, mask = ps.inputs
         L = cfg.num_hidden_layers

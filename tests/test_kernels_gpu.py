@@ -534,6 +534,28 @@ def test_wgrad_fp8_transposed_reads(M, N, K):
         close("wgrad_fp8 amax=%r -> scale 1" % bad, got3, ref, 1e-4)
 
 
+@pytest.mark.parametrize("N,K", [(2304, 768), (3072, 768), (768, 3072), (768, 768), (1024, 1024)])
+def test_gemm_packed_weights_identical(N, K):
+    """nbest_pack_weights + nbest_gemm_args::B_packed: the B tile of the k-contiguous kernels staged by a linear LDS-DMA copy from a
+    pre-packed weight matrix.  Same bytes in the same LDS image, so the result must be BIT-identical to the unpacked call - at the
+    training size (256 x 256 / 256 x 192 tiles take the packed operand) and at a small M (another kernel: the packed operand is ignored)."""
+    bf = torch.bfloat16
+    W = rnd(N, K, dtype=bf, s=0.05, seed=3)
+    Wp, bn = hb.pack_weight(W)
+    assert Wp is not None and bn in (192, 256)
+    assert not torch.equal(Wp.view(-1), W.view(-1))                 # it IS a permutation of the rows / chunks ...
+    assert torch.equal(Wp.view(-1).sort().values, W.view(-1).sort().values)    # ... of the same elements
+    bias = rnd(N, seed=4)
+    for M in (32768 - 88, 424):
+        A = rnd(M, K, dtype=bf, seed=5)
+        R = rnd(M, N, dtype=bf, seed=6)
+        for epi, kw in ((hb.EPI_BIAS, dict(bias=bias)), (hb.EPI_RES, dict(R=R)), (hb.EPI_NONE, {})):
+            ref = hb.gemm(A, W, M, N, K, epilogue=epi, **kw)
+            got = hb.gemm(A, W, M, N, K, epilogue=epi, B_packed=Wp, b_pack_bn=bn, **kw)
+            assert torch.equal(got, ref), "packed B differs: N=%d K=%d M=%d epi=%d" % (N, K, M, epi)
+        close("gemm packed N=%d K=%d M=%d" % (N, K, M), got, A.float() @ W.float().t(), 1e-2)
+
+
 def test_sparse_row_exchange_kernels():
     """nbest_rows_gather / _zero / _add (the word-embedding rows data-parallel ranks exchange, trainer.GradReducer) against the
     torch index ops they replace: bit-exact (copies and one fp32 addition per element), padding slots (id -1, zeros) included."""

@@ -61,6 +61,7 @@ KERNELS = [
     ("sumsq_kernel", 1374208, "per-tensor gradient norms (clip)", None, 85.6e6 * 4 / 1e6),
     ("splitk_reduce2_kernel", None, "split-K reduce of a weight gradient", None, None),
     ("splitk_reduce_kernel", None, "split-K reduce (768x768)", None, None),
+    ("pack_b_kernel", None, "weight matrices packed for the k-contiguous GEMMs (forward copy, dgrad copy)", None, 85e6 * 4 / 1e6),
     ("transpose_multi_kernel", None, "k-contiguous bf16 weight copy for the dgrads", None, 85e6 * 4 / 1e6),
     ("embed_bwd_tables_kernel", None, "embedding backward: position / type tables, LN parameters (folded into embed_bwd_kernel in round 3)", None, None),
     ("embed_bwd_kernel", None, "embedding backward: LN-bwd + word-table atomics", None, None),
