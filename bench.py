@@ -75,7 +75,8 @@ def wgrad_traffic_from_profiles(fp8=False):
             if fp8:
                 is_gemm = "gemm8tt_kernel" in k
             else:
-                is_gemm = ("gemm2_kernel" in k or "gemm_bf16_kernel" in k) and k.rstrip(">").endswith(", 6")   # EPI = F32_SPLITK
+                kk = k.replace(", false>", ">").replace(", true>", ">") if "gemm2_kernel" in k else k    # trailing experiment flag of gemm2_kernel
+                is_gemm = ("gemm2_kernel" in k or "gemm_bf16_kernel" in k) and kk.rstrip(">").endswith(", 6")   # EPI = F32_SPLITK
             if not (is_gemm or ("splitk_reduce8" in k if fp8 else ("splitk_reduce" in k and "reduce8" not in k))):
                 continue
             n, tb = float(row["launches_per_step"]), float(row["traffic_bytes_per_launch"])
