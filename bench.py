@@ -194,7 +194,12 @@ def main():
     ap.add_argument("--no_packed_weights", action="store_true", help="A/B diagnostic: the GEMMs read the weight matrices row by row (round-2 behaviour)")
     a = ap.parse_args()
 
-    rank, world, local = init_distributed()
+    # NBEST_BENCH_REHEARSAL=1: the N ranks share cuda:0 and talk through gloo - the whole multi-rank code path (sharded optimizer,
+    # reduce-to-owner buckets, sparse row exchange, tear-down, rank 0's extra measurements) on a ONE-GPU box; its timings mean nothing
+    rehearsal = os.environ.get("NBEST_BENCH_REHEARSAL") == "1"
+    rank, world, local = init_distributed("gloo" if rehearsal else None)
+    if rehearsal:
+        local = 0
     assert world == a.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -258,6 +263,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         reducer = None            # rank 0's in-step kernel timing below runs its extra steps without a gradient exchange
+        optim.sharded = False     # ... and without the sharded optimizer's collectives (a replicated update of its stale copy: timing only)
 
     if rank == 0:
         note("timed region: %.3f s, %.1f utt/s" % (dt, a.batch * world * a.steps / dt))
@@ -287,6 +293,7 @@ def main():
                                        "off" if a.no_dropout else "on (0.1/0.1/0.3)"),
                        "global_batch": a.batch * world, "seq_len": a.seq_len, "n_best": a.n_best, "parallelism": "dp%d" % world,
                        "add_l2_loss": bool(a.add_l2_loss)},
+            **({"rehearsal": "N ranks on ONE GPU over gloo: code-path check, not a measurement"} if rehearsal else {}),
             "flops_per_utterance": fpu,
             "step_mfma_frac": round(utt * fpu / 1e12 / ((PEAK_FP8_TFLOPS if a.dtype == "fp8w" else PEAK_BF16_TFLOPS) * world), 4),
             "last_loss_per_utt": round(loss / a.batch, 4),

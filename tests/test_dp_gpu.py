@@ -200,3 +200,23 @@ def test_dp_step_equals_single_process(world, B, sparse, dtype_name):
         assert res[r]["gerr"] < 2e-5, res[r]["gerr"]
         assert res[r]["mean_err"] < 2e-6, res[r]["mean_err"]
         assert abs(res[r]["rec_dp"] - res[r]["rec_one"]) <= 1e-5 * abs(res[r]["rec_one"]), (res[r]["rec_dp"], res[r]["rec_one"])
+
+
+@pytest.mark.parametrize("world,model,batch", [(2, "bert", 16), (3, "xlm-roberta", 8)])
+def test_bench_multi_rank_code_path_rehearsal(world, model, batch):
+    """`bench.py --gpus N` end to end on the one-GPU box: NBEST_BENCH_REHEARSAL=1 puts the N ranks on cuda:0 over gloo, so the
+    self-launch through torch.distributed.run, the sharded optimizer, the reduce-to-owner buckets (bert) / the sparse row exchange
+    (xlm-roberta), the barrier-bracketed timed region, the tear-down of the process group and rank 0's in-step kernel timing AFTER the
+    tear-down (a replicated update there: no collective may be left in the step) all run - what the driver's N = 2 / 4 / 8 runs execute
+    over RCCL.  Only the code path is checked; the timings of ranks sharing one GPU mean nothing."""
+    import json
+    import subprocess
+    env = dict(os.environ, NBEST_BENCH_REHEARSAL="1")
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                          "--no_cpu_baseline", "--model", model, "--batch", str(batch)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == world and rec["value"] > 0 and rec["scaling"] == "weak" and "rehearsal" in rec
+    assert rec["roofline"]["achieved"] > 0
