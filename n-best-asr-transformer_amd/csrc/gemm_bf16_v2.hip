@@ -85,6 +85,7 @@ __device__ __forceinline__ void stage_tile2(__amdgpu_buffer_rsrc_t rs, char* til
       int grow = row;
       if constexpr (PW > 0) { const int x = row % PW; grow = row - x + (PW / 16) * (x & 15) + (x >> 4); }
       voff = (uint32_t)(((row0 + grow) * ld + k0 + kc * 8) * 2);
+
     } else {
       constexpr int CPR = ROWS / 8;  // 16-byte chunks per k-row
       const int krow = p / CPR, slot = p % CPR;
@@ -119,6 +120,43 @@ __device__ __forceinline__ void stage_tile_packed(__amdgpu_buffer_rsrc_t rs, cha
       }
     }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, 0, 0, AUX);
+  }
+}
+
+// A operand of the k-contiguous ping-pong kernels, staged in PAIRS of K stages: one LDS-DMA wave-instruction fetches 8 rows x 128
+// contiguous bytes (two stages' worth of a row) instead of 16 rows x 64 - LDS-DMA delivers 33 B/clk/CU on 128-byte segments against 22
+// on 64-byte ones (tools/micro/dma_rate.hip), and the operand delivery is co-critical with the MFMA issue in these kernels.  Pair image:
+// [ROWS][128 B], 16-byte chunk c = 4 * (stage & 1) + kc of a row stored at chunk slot c ^ ((row >> 1) & 7): conflict-free for the
+// fragment reads of either stage (a 16-lane group of ds_read_b128 holds 16 distinct rows, 8 with kc and 8 with kc ^ 1).
+// I0 .. I1: the wave-instructions issued by this call (a pair is issued in two halves, one per slot of the ping-pong loop)
+template <int ROWS, int NT, int AUX, int I0, int I1>
+__device__ __forceinline__ void stage_a_pair(__amdgpu_buffer_rsrc_t rs, char* pair, int64_t row0, int64_t k0, int64_t ld, int tid) {
+  const int wave = tid >> 6;
+  static_assert((ROWS * 8) % NT == 0 && I1 <= (ROWS * 8) / NT, "stage_a_pair: whole instructions only");
+#pragma unroll
+  for (int i = I0; i < I1; ++i) {
+    const int p = i * NT + tid;
+    const int row = p >> 3, slot = p & 7;
+    const int c = slot ^ ((row >> 1) & 7);
+    const uint32_t voff = (uint32_t)(((row0 + row) * ld + k0 + c * 8) * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(pair + (i * NT + wave * 64) * 16), 16, voff, 0, 0, AUX);
+  }
+}
+__device__ __forceinline__ bf16x8 read_frag_pair(const char* pair, int half, int row_base, int lane) {
+  const int row = row_base + (lane & 15);
+  const int c = 4 * half + (lane >> 4);
+  return *(const bf16x8*)(pair + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+}
+// s_waitcnt vmcnt(n) for a wave-uniform even n <= 12
+__device__ __forceinline__ void wait_vm_even(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
   }
 }
 
@@ -384,6 +422,83 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       if (kt + 1 < nk) body(kt + 1, aQ, bQ, aP, bP);
     }
     load_bias();
+  } else if constexpr (NT == 512 && kDirect && BM == 256 && (DIAG & 2048)) {
+    // ---- EXPERIMENT (`make diag DIAG=2048`; measured 25 % SLOWER than per-stage staging - waves wait twice as long for the LDS-DMA,
+    // no LDS bank conflicts; cause not found - kept for the next attempt) ----
+    // ---- ping-pong as below, with the A operand staged in PAIRS of stages (128-byte row segments, stage_a_pair): LDS = 3 pair buffers
+    // of A (2 x A_BYTES each) | STAGES tiles of B | dump slots.  A LOAD slot is as long as an MFMA slot and most of it is LDS-DMA issue,
+    // so a pair is issued in two halves, one per slot: slot j issues half (j & 1) of A pair j/2 + 2 and then B stage j + 3 - four
+    // wave-instructions per slot, as with per-stage staging.  Per wave the issue order is  A0 A1 B0 B1 B2 | A2a B3 | A2b B4 | A3a B5 | ...
+    // and slot kt retires this wave's share of stage kt+1 = B(kt+1), the last instruction of slot kt-2 (A((kt+1)/2) is older): whatever
+    // slots kt-1 and kt issued may stay in flight.
+    constexpr int AP_BYTES = 2 * A_BYTES, NAP = 3;
+    constexpr int NDA = (BM * 8) / NT, NDB = (BN * 4 + NT - 1) / NT, NDH = NDA / 2;
+    static_assert(NDH % 2 == 0 && NDB % 2 == 0 && 2 * NDH + 2 * NDB <= 12, "wait_vm_even covers even counts up to 12");
+    static_assert(STAGES == 4, "pair path: B ring of 4");
+    char* const ldsB = lds + NAP * AP_BYTES;
+    char* const dumpB = ldsB + STAGES * B_BYTES;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    auto issue_b = [&](int st_) {
+      char* dst = ldsB + (st_ & (STAGES - 1)) * B_BYTES;
+      if (b_packed) stage_tile_packed<BN, NT, NB_AUX_B>(rsB, dst, (uint32_t)((tile_n * nkt + st_) * B_BYTES), tid, dumpB);
+      else stage_tile2<TB, BN, NT, NB_AUX_B, kPW>(rsB, dst, n0, kbeg + (int64_t)st_ * BK, ldb_, tid, dumpB);
+    };
+    // slot j: half (j & 1) of the pair holding stages j' + 4, j' + 5 (j' = j rounded down to even); exists iff stage j' + 4 does
+    auto a_half_exists = [&](int j) { return (j & ~1) + 4 < nk; };
+    auto issue_a_half = [&](int j) {
+      const int q = (j >> 1) + 2;
+      char* dst = lds + (q % NAP) * AP_BYTES;
+      const int64_t k0 = kbeg + (int64_t)q * (2 * BK);
+      if (j & 1) stage_a_pair<BM, NT, NB_AUX_A, NDH, NDA>(rsA, dst, m0a, k0, lda_, tid);
+      else stage_a_pair<BM, NT, NB_AUX_A, 0, NDH>(rsA, dst, m0a, k0, lda_, tid);
+    };
+    if (0 < nk) stage_a_pair<BM, NT, NB_AUX_A, 0, NDA>(rsA, lds, m0a, kbeg, lda_, tid);
+    if (2 < nk) stage_a_pair<BM, NT, NB_AUX_A, 0, NDA>(rsA, lds + AP_BYTES, m0a, kbeg + 2 * BK, lda_, tid);
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0)
+      if (s0 < nk) issue_b(s0);
+    {
+      const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;   // B stages issued after B0
+      wait_vm_even(younger * NDB);
+    }
+    __builtin_amdgcn_s_barrier();                 // stage 0 landed for everyone
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
+    bf16x8 af[TMt], bfr[TNt];
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---------------- LOAD slot ----------------
+      const bool ah = a_half_exists(kt), bh = kt + STAGES - 1 < nk;
+      if (ah) issue_a_half(kt);
+      if (bh) issue_b(kt + STAGES - 1);
+      {
+        const char* curB = ldsB + (kt & (STAGES - 1)) * B_BYTES;
+        const char* curA = lds + ((kt >> 1) % NAP) * AP_BYTES;
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<false, BN>(curB, wn * WTN + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < TMt; ++i) af[i] = read_frag_pair(curA, kt & 1, wm * WTM + i * 16, lane);
+      }
+      if (kt + 1 < nk) {   // retire this wave's share of stage kt+1
+        int cnt = (ah ? NDH : 0) + (bh ? NDB : 0);                                                    // this slot
+        if (kt == 0) cnt += (2 < nk ? NDB : 0);                                                      // B2 of the prologue follows B1
+        else cnt += (a_half_exists(kt - 1) ? NDH : 0) + (kt + 2 < nk ? NDB : 0);                      // slot kt-1
+        wait_vm_even(cnt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- MFMA slot ----------------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TMt; ++i)
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count
   } else if constexpr (NT == 512) {
     // ---- ping-pong (8 waves = 2 groups of one wave per SIMD): a group alternates a LOAD slot (fragment
     // reads of stage j, LDS-DMA of stage j+STAGES-1, counted vmcnt) with an MFMA slot (stage j); group 1
@@ -1099,7 +1214,9 @@ static Plan make_plan(const nbest_gemm_args* a) {
 template <int BM, int BN, int WM, int WN, int STAGES, bool TA, bool TB, bool SYM = false>
 static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
-  constexpr int lds_bytes = STAGES * (BM + BN) * BK * 2 + (((BN * 4) % NT) ? (NT / 64) * 1024 : 0);   // + the zero-fill dump slots
+  constexpr int lds_ring = STAGES * (BM + BN) * BK * 2;
+  constexpr int lds_pairs = (!TA && !TB && NT == 512 && BM == 256 && (DIAG & 2048)) ? (3 * 2 * BM + STAGES * BN) * BK * 2 : 0;   // A staged in pairs of stages (3 pair buffers)
+  constexpr int lds_bytes = (lds_pairs > lds_ring ? lds_pairs : lds_ring) + (((BN * 4) % NT) ? (NT / 64) * 1024 : 0);   // + the zero-fill dump slots
 #define L(E)                                                                                                        \
   case E:                                                                                                           \
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WM, WN, STAGES, TA, TB, E, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \

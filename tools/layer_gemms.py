@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--inner", type=int, default=3)
     ap.add_argument("--tag", default="")
     ap.add_argument("--only", default="")
+    ap.add_argument("--no_pack", action="store_true")
     a = ap.parse_args()
     M, H, F = a.M, a.H, a.F
     dev, bf = "cuda", torch.bfloat16
@@ -33,6 +34,11 @@ def main():
     Wqkv, Wo, W1, W2 = r(3 * H, H), r(H, H), r(F, H), r(H, F)
     WqkvT, WoT, W1T, W2T = (w.t().contiguous() for w in (Wqkv, Wo, W1, W2))
     bqkv, bo, b1, b2 = (torch.randn(n, device=dev) for n in (3 * H, H, F, H))
+    # the weight operands as the training step passes them: pre-packed for the kernel's tile (nbest_pack_weights); --no_pack: row by row
+    PK = {}
+    for nm, w in (("qkv", Wqkv), ("o", Wo), ("w1", W1), ("w2", W2), ("qkvT", WqkvT), ("oT", WoT), ("w1T", W1T), ("w2T", W2T)):
+        pw, bn = (None, 0) if a.no_pack else hb.pack_weight(w)
+        PK[nm] = dict(B_packed=pw, b_pack_bn=bn) if pw is not None else {}
     qkv = torch.empty(M, 3 * H, dtype=bf, device=dev)
     oH = torch.empty(M, H, dtype=bf, device=dev)
     oF = torch.empty(M, F, dtype=bf, device=dev)
@@ -43,14 +49,14 @@ def main():
            (("qkv", (3 * H, H)), ("o", (H, H)), ("w1", (F, H)), ("w2", (H, F)))}
     E = hb
     jobs = [
-        ("fwd  qkv       N2304 K768  bias", 2.0 * M * 3 * H * H, lambda: E.gemm(x, Wqkv, M, 3 * H, H, epilogue=E.EPI_BIAS, bias=bqkv, out=qkv)),
-        ("fwd  attn-out  N768  K768  bias+drop+res", 2.0 * M * H * H, lambda: E.gemm(ctx, Wo, M, H, H, epilogue=E.EPI_BIAS_DROP_RES, bias=bo, R=x, out=oH, drop_p=0.1, seed=1, drop_stream=3)),
-        ("fwd  ffn-up    N3072 K768  bias+gelu", 2.0 * M * F * H, lambda: E.gemm(x1, W1, M, F, H, epilogue=E.EPI_BIAS_GELU, bias=b1, U=U, out=oF)),
-        ("fwd  ffn-down  N768  K3072 bias+drop+res", 2.0 * M * F * H, lambda: E.gemm(hact, W2, M, H, F, epilogue=E.EPI_BIAS_DROP_RES, bias=b2, R=x1, out=oH, drop_p=0.1, seed=1, drop_stream=4)),
-        ("dgrd ffn-down  N3072 K768  x gelu' + colsum", 2.0 * M * F * H, lambda: E.gemm(dRd, W2T, M, F, H, epilogue=E.EPI_DGELU, U=U, out=oF, colsum_out=gb1)),
-        ("dgrd ffn-up    N768  K3072 + res", 2.0 * M * F * H, lambda: E.gemm(dBig, W1T, M, H, F, epilogue=E.EPI_RES, R=dR, out=oH)),
-        ("dgrd attn-out  N768  K768  none", 2.0 * M * H * H, lambda: E.gemm(dRd, WoT, M, H, H, out=oH)),
-        ("dgrd qkv       N768  K2304 + res", 2.0 * M * 3 * H * H, lambda: E.gemm(dqkv, WqkvT, M, H, 3 * H, epilogue=E.EPI_RES, R=dR, out=oH)),
+        ("fwd  qkv       N2304 K768  bias", 2.0 * M * 3 * H * H, lambda: E.gemm(x, Wqkv, M, 3 * H, H, epilogue=E.EPI_BIAS, bias=bqkv, out=qkv, **PK['qkv'])),
+        ("fwd  attn-out  N768  K768  bias+drop+res", 2.0 * M * H * H, lambda: E.gemm(ctx, Wo, M, H, H, epilogue=E.EPI_BIAS_DROP_RES, bias=bo, R=x, out=oH, drop_p=0.1, seed=1, drop_stream=3, **PK['o'])),
+        ("fwd  ffn-up    N3072 K768  bias+gelu", 2.0 * M * F * H, lambda: E.gemm(x1, W1, M, F, H, epilogue=E.EPI_BIAS_GELU, bias=b1, U=U, out=oF, **PK['w1'])),
+        ("fwd  ffn-down  N768  K3072 bias+drop+res", 2.0 * M * F * H, lambda: E.gemm(hact, W2, M, H, F, epilogue=E.EPI_BIAS_DROP_RES, bias=b2, R=x1, out=oH, drop_p=0.1, seed=1, drop_stream=4, **PK['w2'])),
+        ("dgrd ffn-down  N3072 K768  x gelu' + colsum", 2.0 * M * F * H, lambda: E.gemm(dRd, W2T, M, F, H, epilogue=E.EPI_DGELU, U=U, out=oF, colsum_out=gb1, **PK['w2T'])),
+        ("dgrd ffn-up    N768  K3072 + res", 2.0 * M * F * H, lambda: E.gemm(dBig, W1T, M, H, F, epilogue=E.EPI_RES, R=dR, out=oH, **PK['w1T'])),
+        ("dgrd attn-out  N768  K768  none", 2.0 * M * H * H, lambda: E.gemm(dRd, WoT, M, H, H, out=oH, **PK['oT'])),
+        ("dgrd qkv       N768  K2304 + res", 2.0 * M * 3 * H * H, lambda: E.gemm(dqkv, WqkvT, M, H, 3 * H, epilogue=E.EPI_RES, R=dR, out=oH, **PK['qkvT'])),
         ("wgrd ffn-down  768x3072", 2.0 * M * F * H, lambda: E.gemm(dRd, hact, H, F, M, 1, 1, E.EPI_F32_SPLITK, out=g32["w2"])),
         ("wgrd ffn-up    3072x768", 2.0 * M * F * H, lambda: E.gemm(dBig, x1, F, H, M, 1, 1, E.EPI_F32_SPLITK, out=g32["w1"])),
         ("wgrd attn-out  768x768", 2.0 * M * H * H, lambda: E.gemm(dRd, ctx, H, H, M, 1, 1, E.EPI_F32_SPLITK, out=g32["o"])),

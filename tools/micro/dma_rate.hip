@@ -11,7 +11,7 @@
 #define LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
-template <int SEG, int MODE>
+template <int SEG, int MODE, int PERM = 0>
 __global__ __launch_bounds__(512) void k(const char* base, int64_t panel_bytes, int ld, int iters, int* sink) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 4 x 32 KiB ring
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -27,7 +27,11 @@ __global__ __launch_bounds__(512) void k(const char* base, int64_t panel_bytes, 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {            // 2048 chunks per stage / 512 threads
         const int p = i * 512 + tid;
-        const int row = p / CPR, c = p % CPR;
+        const int row = p / CPR;
+        int c = p % CPR;
+        if (PERM == 1) c ^= (row >> 1) & (CPR - 1);          // the lanes of a segment fetch its 16-byte chunks in XOR-permuted order (swizzled LDS image)
+        if (PERM == 2) c ^= ((row >> 1) & (CPR - 1)) & ~1;   // permuted in aligned 32-byte pairs only
+        if (PERM == 3) c ^= ((row >> 1) & (CPR - 1)) & ~3;   // permuted in aligned 64-byte quads only
         const uint32_t voff = (uint32_t)((s * rows_per_stage + row) * ld + c * 16);
         if (MODE == 0) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst + (i * 512 + wave * 64) * 16), 16, voff, 0, 0, 0);
@@ -45,15 +49,15 @@ __global__ __launch_bounds__(512) void k(const char* base, int64_t panel_bytes, 
   if (acc == 0x7fffffff) sink[0] = acc;
 }
 
-template <int SEG, int MODE>
+template <int SEG, int MODE, int PERM = 0>
 static void run(const char* name, char* buf, int64_t panel, int ld, int* sink) {
   const int iters = 40, grid = 256;
-  hipFuncSetAttribute((const void*)k<SEG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-  k<SEG, MODE><<<grid, 512, 131072>>>(buf, panel, ld, 2, sink);
+  hipFuncSetAttribute((const void*)k<SEG, MODE, PERM>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  k<SEG, MODE, PERM><<<grid, 512, 131072>>>(buf, panel, ld, 2, sink);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  k<SEG, MODE><<<grid, 512, 131072>>>(buf, panel, ld, iters, sink);
+  k<SEG, MODE, PERM><<<grid, 512, 131072>>>(buf, panel, ld, iters, sink);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -73,6 +77,10 @@ int main() {
   run<128, 0>("LDS-DMA, 128-B segments, stride 1536 B", buf, panel, 1536, sink);
   run<256, 0>("LDS-DMA, 256-B segments, stride 1536 B", buf, panel, 1536, sink);
   run<1024, 0>("LDS-DMA, contiguous (1 KiB rows, stride 1 KiB)", buf, panel, 1024, sink);
+  run<64, 0, 1>("LDS-DMA, 64-B segments, chunks XOR-permuted", buf, panel, 1536, sink);
+  run<128, 0, 1>("LDS-DMA, 128-B segments, chunks XOR-permuted", buf, panel, 1536, sink);
+  run<128, 0, 2>("LDS-DMA, 128-B segments, permuted in 32-B pairs", buf, panel, 1536, sink);
+  run<128, 0, 3>("LDS-DMA, 128-B segments, permuted in 64-B quads", buf, panel, 1536, sink);
   run<64, 1>("VGPR path, 64-B segments, stride 1536 B", buf, panel, 1536, sink);
   run<128, 1>("VGPR path, 128-B segments, stride 1536 B", buf, panel, 1536, sink);
   run<1024, 1>("VGPR path, contiguous", buf, panel, 1024, sink);
