@@ -623,6 +623,38 @@ def test_full_size_batch_additivity(labels):
     assert torch.equal(gf[a.heads_range[0]:a.heads_range[1]], gf2[a.heads_range[0]:a.heads_range[1]])
 
 
+def test_packed_weight_operands_change_nothing(labels):
+    """arena.wpk / wpkt (nbest_pack_weights after every optimizer step) vs the GEMMs reading w16 / w16t row by row, at the full
+    BASELINE configs[1] size where the 256 x 256 / 256 x 192 kernels take the packed operand: scores, loss and every encoder-layer
+    gradient BIT-identical, also after two BertAdam steps (the packed copies follow the weights)."""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    from nbest_amd.optim import HipBertAdam
+    cfg = ncfg.bert_base(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, num_hidden_layers=3)
+    b = synth.nbest_batch(cfg, labels, 256, 128, n_best=5, seed=22, ragged=True)
+    t = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    res = []
+    for packed in (True, False):
+        m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.bfloat16, dropout=0.0)
+        assert m.arena.wpk is not None and m.arena.wpkt is not None
+        if not packed:
+            m.arena.wpk = m.arena.wpkt = None
+        m.load_reference_state(synth.model_state(cfg, labels, seed=4))
+        m.train()
+        opt = HipBertAdam(m, lr=1e-3, bert_lr=1e-4, warmup=0.1, t_total=100)
+        for _ in range(3):
+            out = m.forward_backward(t["ids"], t["labels"], seg_ids=t["seg"])
+            opt.step()
+        torch.cuda.synchronize()
+        a = m.arena
+        lo, hi = a.layer_range[0][0], a.layer_range[-1][1]
+        res.append((out["final"].clone(), out["loss_parts"].clone(), a.g[lo:hi].clone(), a.p[lo:hi].clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert res[0][2].abs().max() > 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "fp8w"])
 def test_training_trajectory_tracks_oracle(dtype, labels):
     """eight optimisation steps (forward, BCE / CE / CLS-MSE losses, backward, BertAdam with warm-up) on changing batches:
