@@ -222,7 +222,7 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
 // after a barrier the per-wave output images reuse its rows, the workgroup needs 2 x Sp x 128 B (32.5 KiB at S = 128) instead
 // of 48.5 KiB - four workgroups per CU instead of three, with the registers capped at 128 for that (launch bounds).  The kernel
 // is bound by memory latency (0.8 MB in flight per workgroup, ~10 us each), not by arithmetic: residency is what it wants.
-template <int NKB>
+template <int NKB, bool DROP>
 __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                             bf16* __restrict__ ctx, float* __restrict__ lse, int S, int heads,
                                                             int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8,
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(
     // normalise (+ dropout) and round to bf16 at once: the probabilities are the A operand of the P.V MFMA (k order of an
     // accumulator tile, see acc_to_frag) - kept as packed bf16 they occupy half the registers of the fp32 scores
     bf16x8 pa[NKB][2];
-    if (drop.thr16 && (S & 1) == 0) {
+    if (DROP && (S & 1) == 0) {
       // registers (2j, 2j+1) hold keys (k, k+1) with k even: with S even they are one element pair of the counter
       // stream, so one hash decides both
       // counter of the pair = (row base + key) / 2 with an even row base: its product with the hash's odd constant splits into a
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float pv = sc[kb][r] * inv;
-          if (drop.thr16) {
+          if (DROP) {
             const int key = 32 * kb + crow(r, hh);
             const bool kp = nb_keep(drop, (uint32_t)((bh * S + qrow) * S + key));
             pv = kp ? pv * drop.scale : 0.f;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(
           }
           pa[kb][r >> 3][r & 7] = (bf16)pv;
         }
-        if (keep_out && drop.thr16) {
+        if (DROP && keep_out) {
           kw |= (uint32_t)__shfl_xor((int)kw, 32, 64);
           if (hh == 0 && qrow < Sp) keep_out[((int64_t)bh * NKB + kb) * Sp + qrow] = kw;
         }
@@ -1068,8 +1068,13 @@ template <int NKB>
 static void launch_fwd(const bf16* qkv, const uint8_t* mask, bf16* ctx, float* lse, int B, int S, int heads, int H, float scale,
                        DropCfg d, hipStream_t st, uint8_t* ctx8, uint32_t* keep) {
   const size_t sm = fwd_lds_bytes(NKB);
-  (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  attn_fwd_bf16_kernel<NKB><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8, keep);
+  if (d.thr16) {     // the dropout-free instantiation (evaluation, parity runs) carries no hash and no keep words: 58 -> 47 us at S = 128
+    (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    attn_fwd_bf16_kernel<NKB, true><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8, keep);
+  } else {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    attn_fwd_bf16_kernel<NKB, false><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8, keep);
+  }
 }
 #ifdef NBEST_EXPERIMENTS
 template <int NKB>
