@@ -190,6 +190,15 @@ int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream);
 size_t nbest_wgrad_fp8_ws_bytes(int64_t M, int64_t N, int64_t K);
 int nbest_wgrad_fp8(const void* dY8, const void* X8, float* dW, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                     int64_t ldc, const uint32_t* a_amax, int accumulate, void* ws, size_t ws_bytes, nbest_stream_t stream);
+/* Two fp8 weight gradients with the same token dimension K and column count N in ONE launch (the e4m3 counterpart of nbest_wgrad_pair;
+ * nbest_encoder_backward pairs the Q|K|V and attention-output gradients of a layer): problem b's 256 x 256 output tiles are appended below
+ * problem a's, each keeps its own gradient scale (amax_a / amax_b), one reduce writes dWa and dWb.  Ma, Mb, N multiples of 256; ws >=
+ * nbest_wgrad_fp8_pair_ws_bytes (0 = the pair does not fit: issue two nbest_wgrad_fp8).                                                */
+size_t nbest_wgrad_fp8_pair_ws_bytes(int64_t Ma, int64_t Mb, int64_t N, int64_t K);
+int nbest_wgrad_fp8_pair(const void* dY8a, const void* X8a, float* dWa, int64_t Ma, int64_t lda_a, int64_t ldb_a, int64_t ldc_a,
+                         const uint32_t* amax_a, const void* dY8b, const void* X8b, float* dWb, int64_t Mb, int64_t lda_b, int64_t ldb_b,
+                         int64_t ldc_b, const uint32_t* amax_b, int64_t N, int64_t K, int accumulate, void* ws, size_t ws_bytes,
+                         nbest_stream_t stream);
 /* bf16 [n] -> e4m3 [n], unit scale, saturating at +-448 (activations that feed an fp8 GEMM); n % 8 == 0 */
 int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream);
 

@@ -103,14 +103,17 @@ static size_t max_splitk_bytes(const nbest_encoder_desc* d, int64_t M) {
     g1.trans_a = g1.trans_b = g2.trans_a = g2.trans_b = 1; g1.epilogue = g2.epilogue = NBEST_EPI_F32_SPLITK; g1.dtype = g2.dtype = NBEST_BF16;
     const size_t bp = nbest_wgrad_pair_ws_bytes(&g1, &g2);
     if (bp > mx) mx = bp;
+    const size_t bp8 = nbest_wgrad_fp8_pair_ws_bytes(3 * (int64_t)d->H, d->H, d->H, M);
+    if (bp8 > mx) mx = bp8;
   }
   return mx;
 }
 
-// bf16 (not the fp8 backward): the attention-output weight gradient of a layer is issued together with the QKV gradient
-// (nbest_wgrad_pair: 3 weight-gradient launches per layer instead of 4) when the pair fits one 256 x 256 split-K launch
+// the attention-output weight gradient of a layer is issued together with the QKV gradient (nbest_wgrad_pair / nbest_wgrad_fp8_pair:
+// 3 weight-gradient launches per layer instead of 4) when the pair fits one 256 x 256 split-K launch
 static bool wgrad_paired(const nbest_encoder_desc* d, bool f8b) {
-  if (d->dtype != NBEST_BF16 || f8b) return false;
+  if (d->dtype != NBEST_BF16) return false;
+  if (f8b) return nbest_wgrad_fp8_pair_ws_bytes(3 * (int64_t)d->H, d->H, d->H, (int64_t)d->B * d->S) > 0;
   nbest_gemm_args g1 = {}, g2 = {};
   g1.M = 3 * (int64_t)d->H; g2.M = d->H; g1.N = g2.N = d->H; g1.K = g2.K = (int64_t)d->B * d->S;
   g1.trans_a = g1.trans_b = g2.trans_a = g2.trans_b = 1; g1.epilogue = g2.epilogue = NBEST_EPI_F32_SPLITK; g1.dtype = g2.dtype = NBEST_BF16;
@@ -408,7 +411,10 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     if (f8b) RUN(dgrad8(dqkv8, 4 * l + 3, o.wqkv, 4 * l + 0, dA, H, 3 * H, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
     else RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st, nullptr, PKT(o.wqkv)));
     stamp(0);
-    if (f8b) RUN(nbest_wgrad_fp8(dqkv8, x8, G(o.wqkv), 3 * H, H, M, 3 * H, H, H, d->gamax_prev + 4 * l + 3, accumulate, slab, w.slab_bytes, stream));
+    if (f8b && paired)
+      RUN(nbest_wgrad_fp8_pair(dqkv8, x8, G(o.wqkv), 3 * H, 3 * H, H, H, d->gamax_prev + 4 * l + 3, dRd8, ctx8, G(o.wo), H, H, H, H,
+                               d->gamax_prev + 4 * l + 2, H, M, accumulate, slab, w.slab_bytes, stream));
+    else if (f8b) RUN(nbest_wgrad_fp8(dqkv8, x8, G(o.wqkv), 3 * H, H, M, 3 * H, H, H, d->gamax_prev + 4 * l + 3, accumulate, slab, w.slab_bytes, stream));
     else if (paired) {
       nbest_gemm_args g1 = {}, g2 = {};
       g1.A = dqkv; g1.B = X(l); g1.C = G(o.wqkv); g1.M = 3 * H; g1.lda = 3 * H;

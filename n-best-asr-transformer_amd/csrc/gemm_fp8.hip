@@ -462,6 +462,12 @@ struct GemmP8T {
   int tiles_m, tiles_n, splits, accumulate;
   uint32_t a_bytes, b_bytes;
   const uint32_t* a_amax;                    // dY8 = e4m3(dY * s): the accumulator is divided by s
+  // second problem of a PAIR (nbest_wgrad_fp8_pair): output rows >= m_split of the virtual [M][N] result are A2^T . B2 with their own
+  // gradient scale (same N and K); m_split = 0: none
+  const uint8_t* A2; const uint8_t* B2;
+  int64_t lda2, ldb2, m_split;
+  uint32_t a2_bytes, b2_bytes;
+  const uint32_t* a_amax2;
 };
 
 __device__ __forceinline__ void stage_tile8t(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t f0, int64_t k0, int64_t ld, int tid) {
@@ -514,9 +520,13 @@ __global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
   const int64_t kbeg = (int64_t)z * p.k_per_split;
   const int64_t kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
   const int nk = (int)((kend - kbeg + BK8 - 1) / BK8);     // token rows past K are zero-filled by the buffer range check
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  const float oscale = p.a_amax ? 1.f / fp8_gscale_of(__uint_as_float(*p.a_amax)) : 1.f;
+  // operands of this tile (workgroup-uniform): the second problem's below m_split
+  const bool second = p.m_split > 0 && m0 >= p.m_split;
+  const int64_t m0a = second ? m0 - p.m_split : m0, lda_ = second ? p.lda2 : p.lda, ldb_ = second ? p.ldb2 : p.ldb;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(second ? (void*)p.A2 : (void*)p.A, 0, second ? p.a2_bytes : p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(second ? (void*)p.B2 : (void*)p.B, 0, second ? p.b2_bytes : p.b_bytes, 0x00020000);
+  const uint32_t* amaxp = second ? p.a_amax2 : p.a_amax;
+  const float oscale = amaxp ? 1.f / fp8_gscale_of(__uint_as_float(*amaxp)) : 1.f;
 
   f32x16 acc[TMb][TNb];
 #pragma unroll
@@ -530,8 +540,8 @@ __global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
 #pragma unroll
   for (int s0 = 0; s0 < STAGES - 1; ++s0) {
     if (s0 < nk) {
-      stage_tile8t(rsA, lds + s0 * STAGE, m0, kbeg + (int64_t)s0 * BK8, p.lda, tid);
-      stage_tile8t(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK8, p.ldb, tid);
+      stage_tile8t(rsA, lds + s0 * STAGE, m0a, kbeg + (int64_t)s0 * BK8, lda_, tid);
+      stage_tile8t(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK8, ldb_, tid);
     }
   }
   {
@@ -550,8 +560,8 @@ __global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
       int nb = buf + STAGES - 1;
       if (nb >= STAGES) nb -= STAGES;
       const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK8;
-      stage_tile8t(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-      stage_tile8t(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+      stage_tile8t(rsA, lds + nb * STAGE, m0a, k0, lda_, tid);
+      stage_tile8t(rsB, lds + nb * STAGE + A_BYTES, n0, k0, ldb_, tid);
     }
     const char* cur = lds + buf * STAGE;
 #pragma unroll
@@ -620,12 +630,13 @@ __global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce8_kernel(const float* __restrict__ slab, float* __restrict__ C, int64_t MN,
-                                                             int64_t N, int64_t ldc, int splits, int accumulate) {
+                                                             int64_t N, int64_t ldc, int splits, int accumulate,
+                                                             float* __restrict__ C2, int64_t m_split, int64_t ldc2) {
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * blockDim.x * 4) {
     f32x4 s = *(const f32x4*)(slab + i);
     for (int z = 1; z < splits; ++z) s += *(const f32x4*)(slab + (int64_t)z * MN + i);
     const int64_t m = i / N, n = i - m * N;
-    float* c = C + m * ldc + n;
+    float* c = (m < m_split) ? C + m * ldc + n : C2 + (m - m_split) * ldc2 + n;   // rows >= m_split: the second output of a pair
     if (accumulate) s += *(const f32x4*)c;
     *(f32x4*)c = s;
   }
@@ -678,36 +689,73 @@ extern "C" size_t nbest_wgrad_fp8_ws_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 // dW[M][N] (fp32, ldc) (+)= sum_k dY8[k][M-features] * X8[k][N-features] / s(a_amax); dY8 [K tokens][lda], X8 [K tokens][ldb] e4m3
+// second problem (pair): dY8b / X8b / dWb / Mb rows / its own scale, appended below the first's output tiles
+static int wgrad_fp8_impl(const void* dY8, const void* X8, float* dW, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                          int64_t ldc, const uint32_t* a_amax, const void* dY8b, const void* X8b, float* dWb, int64_t Mb, int64_t ldab,
+                          int64_t ldbb, int64_t ldcb, const uint32_t* a_amaxb, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int64_t Mv = M + Mb;     // rows of the virtual output
+  GemmP8T p;
+  p.A = (const uint8_t*)dY8; p.B = (const uint8_t*)X8; p.C = dW; p.slab = (float*)ws;
+  p.M = Mv; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  plan8tt(Mv, N, K, &p.splits, &p.k_per_split);
+  p.tiles_m = (int)(Mv / 256); p.tiles_n = (int)(N / 256);
+  p.accumulate = accumulate;
+  const int64_t ab = (K - 1) * lda + M, bb = (K - 1) * ldb + N;
+  NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "wgrad_fp8: operand larger than 4 GiB");
+  p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
+  p.a_amax = a_amax;
+  p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.m_split = 0; p.a2_bytes = p.b2_bytes = 0; p.a_amax2 = nullptr;
+  if (Mb > 0) {
+    const int64_t ab2 = (K - 1) * ldab + Mb, bb2 = (K - 1) * ldbb + N;
+    NB_CHECK(ab2 < ((int64_t)1 << 32) && bb2 < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "wgrad_fp8: operand larger than 4 GiB");
+    NB_CHECK(p.splits > 1, NBEST_ERR_SHAPE, "wgrad_fp8_pair: needs a split-K plan");
+    p.A2 = (const uint8_t*)dY8b; p.B2 = (const uint8_t*)X8b; p.lda2 = ldab; p.ldb2 = ldbb; p.m_split = M;
+    p.a2_bytes = (uint32_t)ab2; p.b2_bytes = (uint32_t)bb2; p.a_amax2 = a_amaxb;
+  }
+  if (p.splits > 1) NB_CHECK(ws && ws_bytes >= (size_t)p.splits * Mv * N * sizeof(float), NBEST_ERR_WORKSPACE, "wgrad_fp8: workspace too small");
+  constexpr int lds_bytes = 4 * 2 * 256 * BK8;
+  (void)hipFuncSetAttribute((const void*)gemm8tt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  gemm8tt_kernel<<<p.tiles_m * p.tiles_n * p.splits, 512, lds_bytes, st>>>(p);
+  NB_LAUNCH_CHECK();
+  if (p.splits > 1) {
+    const int64_t MN = Mv * N;
+    int64_t g = (MN / 4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    splitk_reduce8_kernel<<<(int)g, 256, 0, st>>>(p.slab, dW, MN, N, ldc, p.splits, accumulate, dWb, Mb > 0 ? M : Mv, ldcb);
+    NB_LAUNCH_CHECK();
+  }
+  return NBEST_OK;
+}
+
 extern "C" int nbest_wgrad_fp8(const void* dY8, const void* X8, float* dW, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                                int64_t ldc, const uint32_t* a_amax, int accumulate, void* ws, size_t ws_bytes, nbest_stream_t stream) {
   NB_CHECK(dY8 && X8 && dW && M > 0 && N > 0 && K > 0, NBEST_ERR_ARG, "wgrad_fp8: bad arguments");
   NB_CHECK(M % 256 == 0 && N % 256 == 0, NBEST_ERR_SHAPE, "wgrad_fp8: output %lld x %lld must be multiples of 256", (long long)M, (long long)N);
   NB_CHECK(lda % 16 == 0 && ldb % 16 == 0 && ldc % 8 == 0 && ((uintptr_t)dY8 & 15) == 0 && ((uintptr_t)X8 & 15) == 0 && ((uintptr_t)dW & 15) == 0,
            NBEST_ERR_ALIGN, "wgrad_fp8: alignment");
-  GemmP8T p;
-  p.A = (const uint8_t*)dY8; p.B = (const uint8_t*)X8; p.C = dW; p.slab = (float*)ws;
-  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-  plan8tt(M, N, K, &p.splits, &p.k_per_split);
-  p.tiles_m = (int)(M / 256); p.tiles_n = (int)(N / 256);
-  p.accumulate = accumulate;
-  const int64_t ab = (K - 1) * lda + M, bb = (K - 1) * ldb + N;
-  NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "wgrad_fp8: operand larger than 4 GiB");
-  p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
-  p.a_amax = a_amax;
-  if (p.splits > 1) NB_CHECK(ws && ws_bytes >= (size_t)p.splits * M * N * sizeof(float), NBEST_ERR_WORKSPACE, "wgrad_fp8: workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  constexpr int lds_bytes = 4 * 2 * 256 * BK8;
-  (void)hipFuncSetAttribute((const void*)gemm8tt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-  gemm8tt_kernel<<<p.tiles_m * p.tiles_n * p.splits, 512, lds_bytes, st>>>(p);
-  NB_LAUNCH_CHECK();
-  if (p.splits > 1) {
-    const int64_t MN = M * N;
-    int64_t g = (MN / 4 + 255) / 256;
-    if (g > 2048) g = 2048;
-    splitk_reduce8_kernel<<<(int)g, 256, 0, st>>>(p.slab, dW, MN, N, ldc, p.splits, accumulate);
-    NB_LAUNCH_CHECK();
-  }
-  return NBEST_OK;
+  return wgrad_fp8_impl(dY8, X8, dW, M, N, K, lda, ldb, ldc, a_amax, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, accumulate, ws, ws_bytes,
+                        (hipStream_t)stream);
+}
+
+// two fp8 weight gradients with the same K (tokens) and N in one launch (the e4m3 counterpart of nbest_wgrad_pair): the 256 x 256 output
+// tiles of the second problem are appended below the first's, each problem keeps its own gradient scale; one reduce writes both outputs
+extern "C" size_t nbest_wgrad_fp8_pair_ws_bytes(int64_t Ma, int64_t Mb, int64_t N, int64_t K) {
+  if (Ma <= 0 || Mb <= 0 || Ma % 256 || Mb % 256 || N % 256) return 0;
+  int sp; int64_t kps;
+  plan8tt(Ma + Mb, N, K, &sp, &kps);
+  return sp > 1 ? (size_t)sp * (Ma + Mb) * N * sizeof(float) : 0;
+}
+extern "C" int nbest_wgrad_fp8_pair(const void* dY8a, const void* X8a, float* dWa, int64_t Ma, int64_t lda_a, int64_t ldb_a, int64_t ldc_a,
+                                    const uint32_t* amax_a, const void* dY8b, const void* X8b, float* dWb, int64_t Mb, int64_t lda_b,
+                                    int64_t ldb_b, int64_t ldc_b, const uint32_t* amax_b, int64_t N, int64_t K, int accumulate, void* ws,
+                                    size_t ws_bytes, nbest_stream_t stream) {
+  NB_CHECK(dY8a && X8a && dWa && dY8b && X8b && dWb && N > 0 && K > 0, NBEST_ERR_ARG, "wgrad_fp8_pair: bad arguments");
+  NB_CHECK(nbest_wgrad_fp8_pair_ws_bytes(Ma, Mb, N, K) > 0, NBEST_ERR_SHAPE, "wgrad_fp8_pair: Ma, Mb, N must be multiples of 256 and the pair must split K");
+  NB_CHECK(lda_a % 16 == 0 && ldb_a % 16 == 0 && ldc_a % 8 == 0 && lda_b % 16 == 0 && ldb_b % 16 == 0 && ldc_b % 8 == 0 &&
+               (((uintptr_t)dY8a | (uintptr_t)X8a | (uintptr_t)dWa | (uintptr_t)dY8b | (uintptr_t)X8b | (uintptr_t)dWb) & 15) == 0,
+           NBEST_ERR_ALIGN, "wgrad_fp8_pair: alignment");
+  return wgrad_fp8_impl(dY8a, X8a, dWa, Ma, N, K, lda_a, ldb_a, ldc_a, amax_a, dY8b, X8b, dWb, Mb, lda_b, ldb_b, ldc_b, amax_b, accumulate, ws,
+                        ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream) {

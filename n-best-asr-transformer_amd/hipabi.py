@@ -21,7 +21,7 @@ EXPORTS = [
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_wgrad_launches_per_layer", "nbest_encoder_forward",
-    "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_wgrad_fp8", "nbest_wgrad_fp8_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
+    "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_wgrad_fp8", "nbest_wgrad_fp8_ws_bytes", "nbest_wgrad_fp8_pair", "nbest_wgrad_fp8_pair_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
 ]
 
 
@@ -138,6 +138,9 @@ def lib():
         L.nbest_wgrad_fp8_ws_bytes.restype = C.c_size_t
         L.nbest_wgrad_fp8_ws_bytes.argtypes = [i64, i64, i64]
         L.nbest_wgrad_fp8.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, i32, vp, sz, vp]
+        L.nbest_wgrad_fp8_pair_ws_bytes.restype = C.c_size_t
+        L.nbest_wgrad_fp8_pair_ws_bytes.argtypes = [i64, i64, i64, i64]
+        L.nbest_wgrad_fp8_pair.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp, i64, i64, i32, vp, sz, vp]
         L.nbest_quantize_weights_fp8.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
         L.nbest_gemm_fp8_ws_bytes.restype = C.c_size_t
         L.nbest_gemm_fp8_ws_bytes.argtypes = [C.POINTER(GemmFp8Args)]
@@ -330,6 +333,19 @@ def wgrad_fp8(dY8, X8, M, N, K, a_amax=None, out=None, accumulate=False):
     check(lib().nbest_wgrad_fp8(ptr(dY8), ptr(X8), ptr(out), M, N, K, dY8.stride(0), X8.stride(0), out.stride(0), ptr(a_amax),
                                 int(accumulate), ptr(ws), ws.numel(), stream_ptr()), "wgrad_fp8")
     return out
+
+
+def wgrad_fp8_pair(dY8a, X8a, dY8b, X8b, amax_a=None, amax_b=None, outs=None, accumulate=False):
+    """(dY8a^T . X8a / s_a, dY8b^T . X8b / s_b) in fp32 by ONE launch; dY8_i [K, M_i], X8_i [K, N] token-major e4m3 bytes"""
+    K, N = X8a.shape
+    Ma, Mb = dY8a.shape[1], dY8b.shape[1]
+    oa, ob = outs if outs is not None else (torch.zeros(Ma, N, dtype=torch.float32, device=X8a.device),
+                                            torch.zeros(Mb, N, dtype=torch.float32, device=X8a.device))
+    ws = _ws(lib().nbest_wgrad_fp8_pair_ws_bytes(Ma, Mb, N, K), X8a.device)
+    check(lib().nbest_wgrad_fp8_pair(ptr(dY8a), ptr(X8a), ptr(oa), Ma, dY8a.stride(0), X8a.stride(0), oa.stride(0), ptr(amax_a),
+                                     ptr(dY8b), ptr(X8b), ptr(ob), Mb, dY8b.stride(0), X8b.stride(0), ob.stride(0), ptr(amax_b),
+                                     N, K, int(accumulate), ptr(ws), ws.numel(), stream_ptr()), "wgrad_fp8_pair")
+    return oa, ob
 
 
 def layernorm_fwd(x, gamma, beta, eps):

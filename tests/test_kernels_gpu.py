@@ -534,6 +534,28 @@ def test_wgrad_fp8_transposed_reads(M, N, K):
         close("wgrad_fp8 amax=%r -> scale 1" % bad, got3, ref, 1e-4)
 
 
+@pytest.mark.parametrize("H,K", [(768, 5000), (1024, 2048), (768, 32768)])
+def test_wgrad_fp8_pair(H, K):
+    """nbest_wgrad_fp8_pair: the e4m3 Q|K|V ([3H, H]) and attention-output ([H, H]) weight gradients of a layer in one launch, each with
+    its OWN gradient scale, against the fp32 products of the dequantised operands (tolerance of the single-problem test) - rows of dQ|dK|dV
+    with leading dimension 3H, ragged K, accumulate into existing gradients."""
+    g = torch.Generator().manual_seed(H + K)
+    dqkv8 = _e4m3(torch.randn(K, 3 * H, generator=g)).to(DEV)
+    x8 = _e4m3(torch.randn(K, H, generator=g)).to(DEV)
+    dy8 = _e4m3(torch.randn(K, H, generator=g)).to(DEV)
+    ctx8 = _e4m3(torch.randn(K, H, generator=g)).to(DEV)
+    r1, r2 = dqkv8.float().t() @ x8.float(), dy8.float().t() @ ctx8.float()
+    u8 = lambda t: t.view(torch.uint8)
+    g1, g2 = hb.wgrad_fp8_pair(u8(dqkv8), u8(x8), u8(dy8), u8(ctx8))
+    close("wgrad_fp8_pair QKV  H=%d K=%d" % (H, K), g1, r1, 1e-4)
+    close("wgrad_fp8_pair attn H=%d K=%d" % (H, K), g2, r2, 1e-4)
+    a1 = torch.tensor([3.0], device=DEV).view(torch.int32)     # scale 16
+    a2 = torch.tensor([0.4], device=DEV).view(torch.int32)     # scale 2^floor(log2(56 / 0.4)) = 128
+    h1, h2 = hb.wgrad_fp8_pair(u8(dqkv8), u8(x8), u8(dy8), u8(ctx8), amax_a=a1, amax_b=a2, outs=(g1.clone(), g2.clone()), accumulate=True)
+    close("wgrad_fp8_pair scaled + accumulate QKV", h1, r1 * (1 + 1 / 16.0), 1e-4)
+    close("wgrad_fp8_pair scaled + accumulate attn", h2, r2 * (1 + 1 / 128.0), 1e-4)
+
+
 @pytest.mark.parametrize("N,K", [(2304, 768), (3072, 768), (768, 3072), (768, 768), (1024, 1024)])
 def test_gemm_packed_weights_identical(N, K):
     """nbest_pack_weights + nbest_gemm_args::B_packed: the B tile of the k-contiguous kernels staged by a linear LDS-DMA copy from a
