@@ -211,7 +211,7 @@ def main():
     model = NBestSTCModel(cfg, labels, device=dev, compute_dtype=dtype, dropout=0.0 if a.no_dropout else 0.3, seed=999,
                           fp8_forward=(a.dtype == "fp8w"))
     if a.no_packed_weights:
-        model.arena.wpk = model.arena.wpkt = None
+        model.arena.wpk = model.arena.wpkt = model.arena.w8p = model.arena.w8tp = None
     model.load_reference_state(synth.model_state(cfg, labels, seed=999))     # random init of the named architecture
     broadcast_parameters(model)
     model.train()

@@ -180,6 +180,10 @@ typedef struct nbest_gemm_fp8_args {
   int32_t pad;
   void* ws;
   size_t ws_bytes;
+  const void* B_packed; /* optional: B pre-packed by nbest_pack_weights_fp8 for tiles of b_pack_bn columns (256 | 128); used when the kernel
+                           chosen for the shape has that tile width, otherwise B is read.  Identical results.                        */
+  int32_t b_pack_bn;
+  int32_t pad3;
 } nbest_gemm_fp8_args;
 size_t nbest_gemm_fp8_ws_bytes(const nbest_gemm_fp8_args* a);
 int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream);
@@ -359,6 +363,10 @@ int nbest_transpose_weights(const void* src, void* dst, const nbest_matrix_desc*
  * Once per optimizer step, beside nbest_transpose_weights / the bf16 copy refresh of nbest_bertadam_step (the nn.Linear weights of the
  * installed modeling_bert.py:154-177, 282-293, 325-351 do not change inside a step).                                                   */
 int nbest_pack_bn(int64_t N);
+/* the same for the e4m3 copies read by nbest_gemm_fp8 (descs[].pad = nbest_pack_bn_fp8(rows, cols) = 256 | 128, cols % 64 == 0,
+ * tile_start / n_stages in units of (tile column, 64-byte K stage) blocks; one byte per element at the arena's element offsets)      */
+int nbest_pack_bn_fp8(int64_t N, int64_t K);
+int nbest_pack_weights_fp8(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_stages, nbest_stream_t stream);
 int nbest_pack_weights(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_stages, nbest_stream_t stream);
 /* fp32 -> bf16 copy of an arena (initial compute copy / after loading a checkpoint) */
 int nbest_cast_f32_to_bf16(const float* src, void* dst, int64_t n, nbest_stream_t stream);
@@ -411,6 +419,9 @@ typedef struct nbest_encoder_desc {
    * the dgrad GEMMs (wpkt: packed from the TRANSPOSED copy wts_t), at the arena's element offsets; NULL = the GEMMs read wts / wts_t */
   const void* wpk;
   const void* wpkt;
+  /* optional (fp8w): w8 / w8t packed by nbest_pack_weights_fp8, at the arena's element offsets (bytes) */
+  const void* w8p;
+  const void* w8tp;
 } nbest_encoder_desc;
 size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
 size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);

@@ -112,6 +112,7 @@ class ParamArena:
         self.w8 = self.w8t = self.w8_inv_scale = self._w8_ws = self.gamax = None
         self._tdescs = None
         self.wpk = self.wpkt = None     # packed copies for the bf16 GEMMs (dropped when the fp8 mode is enabled: its GEMMs read w8 / w8t)
+        self.w8p = self.w8tp = None
         self._pdescs = None
         if self.w16 is not None and self.device.type == "cuda":
             self.w16t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
@@ -182,6 +183,9 @@ class ParamArena:
             hb.check(hb.lib().nbest_quantize_weights_fp8(hb.ptr(self.p), hb.ptr(self.w8), hb.ptr(self.w8t), hb.ptr(d), n, t,
                                                          hb.ptr(self.w8_inv_scale), hb.ptr(self._w8_ws), self._w8_ws.numel(),
                                                          hb.stream_ptr()), "quantize_weights_fp8")
+            if getattr(self, "w8p", None) is not None:
+                for src, dst, (pd, pn, pt) in ((self.w8, self.w8p, self._p8descs[0]), (self.w8t, self.w8tp, self._p8descs[1])):
+                    hb.check(hb.lib().nbest_pack_weights_fp8(hb.ptr(src), hb.ptr(dst), hb.ptr(pd), pn, pt, hb.stream_ptr()), "pack_weights_fp8")
 
     def refresh_w16t(self):
         d, n, t = self._tdescs
@@ -206,6 +210,24 @@ class ParamArena:
             self.gamax = [torch.zeros(n, dtype=torch.int32, device=self.device) for _ in range(2)]
             self.w8_inv_scale = torch.ones(n, dtype=torch.float32, device=self.device)
             self._w8_ws = torch.zeros(4 * n + 16, dtype=torch.uint8, device=self.device)
+            # w8 / w8t packed for gemm8_kernel's tiles (nbest_pack_weights_fp8), as wpk / wpkt for the bf16 kernels
+            self.w8p = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
+            self.w8tp = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
+            H, F = self.cfg.hidden_size, self.cfg.intermediate_size
+            mats = []
+            for o in self.layer_offsets:
+                mats += [(o.wqkv, 3 * H, H), (o.wo, H, H), (o.w1, F, H), (o.w2, H, F)]
+            self._p8descs = []
+            for transposed in (False, True):
+                parr = (hb.MatrixDesc * len(mats))()
+                t = 0
+                for i, (off, r, c) in enumerate(mats):
+                    nn, kk = (c, r) if transposed else (r, c)
+                    bn = hb.lib().nbest_pack_bn_fp8(nn, kk)
+                    assert bn > 0 and kk % 64 == 0 and nn % bn == 0, "encoder matrix %d x %d has no packed e4m3 form" % (nn, kk)
+                    parr[i].offset, parr[i].rows, parr[i].cols, parr[i].tile_start, parr[i].pad = off, nn, kk, t, bn
+                    t += (nn // bn) * (kk // 64)
+                self._p8descs.append((torch.frombuffer(bytearray(bytes(parr)), dtype=torch.uint8).to(self.device), len(mats), t))
             self.refresh_transposed()
 
     def load_state(self, sd, strict=True):

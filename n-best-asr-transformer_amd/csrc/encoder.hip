@@ -242,6 +242,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     nbest_gemm_fp8_args g = {};
     g.A = A8; g.B = (const uint8_t*)d->w8 + w_off; g.C = Cout; g.bias = bias; g.R = R; g.U = U; g.C8 = C8;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N; g.ldu = N; g.ldc8 = N;
+    if (d->w8p) { g.B_packed = (const uint8_t*)d->w8p + w_off; g.b_pack_bn = nbest_pack_bn_fp8(N, K); }
     g.epilogue = epi; g.out_scale = 1.f; g.out_scale_dev = d->w8_inv_scale + mat; g.drop_p = drop_p; g.drop_stream = stream_id; g.seed = d->seed;
     return nbest_gemm_fp8(&g, stream);
   };
@@ -346,6 +347,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     nbest_gemm_fp8_args g = {};
     g.A = A8; g.B = (const uint8_t*)d->w8t + w_off; g.C = Cout; g.R = R; g.U = U; g.C8 = C8;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N; g.ldu = N; g.ldc8 = N;
+    if (d->w8tp) { g.B_packed = (const uint8_t*)d->w8tp + w_off; g.b_pack_bn = nbest_pack_bn_fp8(N, K); }
     g.epilogue = epi; g.out_scale = 1.f; g.out_scale_dev = d->w8_inv_scale + mat; g.a_amax = d->gamax_prev + a_idx;
     if (c_idx >= 0) { g.c8_amax_prev = d->gamax_prev + c_idx; g.c8_amax_new = d->gamax_new + c_idx; }
     g.colsum_out = colsum; g.colsum_accumulate = accumulate; g.ws = red1; g.ws_bytes = w.red_bytes;

@@ -47,6 +47,8 @@ struct GemmP8 {
   DropCfg drop;
   int stream_out;
   int gn;                      // tile columns per L2 group (common.h nb_tile_coords)
+  const uint8_t* Bp;           // B pre-packed for this tile width (nbest_pack_weights_fp8): (tile column, K stage) images, contiguous; or nullptr
+  uint32_t bp_bytes;
 };
 
 #ifdef NBEST_EXPERIMENTS
@@ -70,6 +72,15 @@ __device__ __forceinline__ void stage_tile8(__amdgpu_buffer_rsrc_t rs, char* til
     const uint32_t voff = (uint32_t)((row0 + row) * ld + k0 + kc * 16);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, voff, 0, 0, AUX);
   }
+}
+
+// the same B tile from a PRE-PACKED operand (pack_b8_kernel): a linear copy, 1 KiB contiguous per wave-instruction
+template <int ROWS, int NT, int AUX = 0>
+__device__ __forceinline__ void stage_tile8_packed(__amdgpu_buffer_rsrc_t rs, char* tile, uint32_t stage_byte0, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < ROWS * 4 / NT; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(tile + (i * NT + wave * 64) * 16), 16, stage_byte0 + (uint32_t)(i * NT + tid) * 16u, 0, 0, AUX);
 }
 
 __device__ __forceinline__ i32x8 read_frag8(const char* tile, int row_base, int lane) {
@@ -100,7 +111,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
   const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
   const int nk = (DIAG8 & 2048) ? 1 : (int)(p.K / BK8);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  const bool b_packed = p.Bp != nullptr;                        // workgroup-uniform
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(b_packed ? (void*)p.Bp : (void*)p.B, 0, b_packed ? p.bp_bytes : p.b_bytes, 0x00020000);
+  const int nkt = (int)(p.K / BK8);
+  constexpr int BNc = 64 * WN, B_BYTESc = BNc * BK8;
 
   constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES);
   constexpr bool kHasR = (EPI == NBEST_EPI_BIAS_DROP_RES || EPI == NBEST_EPI_RES);
@@ -143,7 +157,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
         stage_tile8<BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
-        stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
+        if (b_packed) stage_tile8_packed<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, (uint32_t)((tile_n * nkt + s0) * B_BYTESc), tid);
+        else stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
       }
     }
     {
@@ -163,7 +178,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = (int64_t)(kt + STAGES - 1) * BK8;
         stage_tile8<BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-        stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+        if (b_packed) stage_tile8_packed<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, (uint32_t)((tile_n * nkt + kt + STAGES - 1) * B_BYTESc), tid);
+        else stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
       }
       const char* cur = lds + buf * STAGE;
   #pragma unroll
@@ -211,7 +227,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
     for (int s0 = 0; s0 < STAGES - 1; ++s0) {
       if (s0 < nk) {
         stage_tile8<BM, NT, NB_AUX_A>(rsA, lds + s0 * STAGE, m0, (int64_t)s0 * BK8, p.lda, tid);
-        stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
+        if (b_packed) stage_tile8_packed<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, (uint32_t)((tile_n * nkt + s0) * B_BYTESc), tid);
+        else stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + s0 * STAGE + A_BYTES, n0, (int64_t)s0 * BK8, p.ldb, tid);
       }
     }
     int buf = 0;
@@ -225,7 +242,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
         if (nb >= STAGES) nb -= STAGES;
         const int64_t k0 = (int64_t)(kt + STAGES - 1) * BK8;
         stage_tile8<BM, NT, NB_AUX_A>(rsA, lds + nb * STAGE, m0, k0, p.lda, tid);
-        stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
+        if (b_packed) stage_tile8_packed<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, (uint32_t)((tile_n * nkt + kt + STAGES - 1) * B_BYTESc), tid);
+        else stage_tile8<BN, NT, NB_AUX_B>(rsB, lds + nb * STAGE + A_BYTES, n0, k0, p.ldb, tid);
       }
       const char* cur = lds + buf * STAGE;
 #pragma unroll
@@ -441,6 +459,26 @@ __global__ __launch_bounds__(256) void quant_w8t_kernel(const float* __restrict_
   for (int i = 0; i < 16; ++i) {
     const int c = c0 + ty + 4 * i, r = r0 + tx;
     if (c < d.cols && r < d.rows) o[(int64_t)c * d.rows + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+// e4m3 B operand ([N][K] bytes, k-contiguous) -> the order gemm8_kernel stages it: per (tile column, 64-byte K stage) the bn x 64 LDS image
+// (16-byte chunk slot ^ ((row >> 2) & 3), as stage_tile8), contiguous.  desc.pad = bn (256 | 128), tile_start = first block of the matrix.
+__global__ __launch_bounds__(256) void pack_b8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                      const nbest_matrix_desc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const nbest_matrix_desc d = descs[lo];
+  const int bn = d.pad, nk = d.cols / BK8, t = blockIdx.x - d.tile_start, tile_n = t / nk, kt = t - tile_n * nk;
+  const uint8_t* s = src + d.offset + ((int64_t)tile_n * bn) * d.cols + (int64_t)kt * BK8;
+  uint8_t* o = dst + d.offset + ((int64_t)tile_n * nk + kt) * bn * BK8;
+  for (int p = threadIdx.x; p < bn * 4; p += blockDim.x) {
+    const int row = p >> 2, slot = p & 3;
+    const int kc = slot ^ ((row >> 2) & 3);
+    *(i32x4*)(o + (int64_t)p * 16) = *(const i32x4*)(s + (int64_t)row * d.cols + kc * 16);
   }
 }
 
@@ -758,6 +796,19 @@ extern "C" int nbest_wgrad_fp8_pair(const void* dY8a, const void* X8a, float* dW
                         ws_bytes, (hipStream_t)stream);
 }
 
+// tile width gemm8_kernel uses for an [N][K] e4m3 weight at training-size token counts (its wn rule at M = 32 768)
+extern "C" int nbest_pack_bn_fp8(int64_t N, int64_t K) {
+  if (N % 256) return 0;
+  return (N <= 768 && K <= 1024) ? 128 : 256;
+}
+extern "C" int nbest_pack_weights_fp8(const void* src, void* dst, const nbest_matrix_desc* descs, int n_matrices, int n_stages,
+                                      nbest_stream_t stream) {
+  NB_CHECK(src && dst && descs && n_matrices > 0 && n_stages > 0 && src != dst, NBEST_ERR_ARG, "pack_weights_fp8: bad arguments");
+  pack_b8_kernel<<<n_stages, 256, 0, (hipStream_t)stream>>>((const uint8_t*)src, (uint8_t*)dst, descs, n_matrices);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
 extern "C" int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream) {
   NB_CHECK(src && dst && n > 0 && n % 8 == 0, NBEST_ERR_ARG, "cast_bf16_to_fp8: bad arguments");
   int64_t g = (n / 8 + 255) / 256;
@@ -833,6 +884,11 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
 #endif
   p.tiles_m = (int)((a->M + 255) / 256);
   p.tiles_n = (int)(a->N / (64 * wn));
+  p.Bp = nullptr; p.bp_bytes = 0;
+  if (a->B_packed && a->b_pack_bn == 64 * wn && a->ldb == a->K && a->N * a->K < ((int64_t)1 << 32) && ((uintptr_t)a->B_packed & 15) == 0) {
+    p.Bp = (const uint8_t*)a->B_packed;
+    p.bp_bytes = (uint32_t)(a->N * a->K);
+  }
   const int64_t ab = (a->M - 1) * a->lda + a->K, bb = (a->N - 1) * a->ldb + a->K;
   NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "gemm_fp8: operand larger than 4 GiB");
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;

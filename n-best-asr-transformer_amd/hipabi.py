@@ -17,7 +17,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_DGELU, EPI_RES, EPI_F3
 
 EXPORTS = [
     "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes", "nbest_rows_gather", "nbest_rows_zero", "nbest_rows_add",
-    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_wgrad_pair_ws_bytes", "nbest_wgrad_pair", "nbest_pack_bn", "nbest_pack_weights", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
+    "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_wgrad_pair_ws_bytes", "nbest_wgrad_pair", "nbest_pack_bn", "nbest_pack_weights", "nbest_pack_bn_fp8", "nbest_pack_weights_fp8", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
     "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_wgrad_launches_per_layer", "nbest_encoder_forward",
@@ -42,7 +42,8 @@ class GemmFp8Args(C.Structure):
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64), ("ldu", C.c_int64), ("ldc8", C.c_int64),
                 ("epilogue", C.c_int32), ("out_scale", C.c_float), ("drop_p", C.c_float), ("drop_stream", C.c_uint32), ("seed", C.c_uint64),
                 ("out_scale_dev", C.c_void_p), ("a_amax", C.c_void_p), ("c8_amax_prev", C.c_void_p), ("c8_amax_new", C.c_void_p),
-                ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("pad", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+                ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int32), ("pad", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("B_packed", C.c_void_p), ("b_pack_bn", C.c_int32), ("pad3", C.c_int32)]
 
 
 class LabelSpaceC(C.Structure):
@@ -74,7 +75,7 @@ class EncoderDesc(C.Structure):
                 ("wgrad_events_n", C.c_int32), ("wgrad_events", C.POINTER(C.c_void_p)),
                 ("w8", C.c_void_p), ("w8_inv_scale", C.c_void_p), ("w8t", C.c_void_p), ("gamax_prev", C.c_void_p),
                 ("gamax_new", C.c_void_p), ("fp8_bwd", C.c_int32), ("pad2", C.c_int32),
-                ("wpk", C.c_void_p), ("wpkt", C.c_void_p)]
+                ("wpk", C.c_void_p), ("wpkt", C.c_void_p), ("w8p", C.c_void_p), ("w8tp", C.c_void_p)]
 
 
 _lib = None
@@ -133,6 +134,8 @@ def lib():
         L.nbest_transpose_weights.argtypes = [vp, vp, vp, i32, i32, vp]
         L.nbest_pack_bn.argtypes = [i64]
         L.nbest_pack_weights.argtypes = [vp, vp, vp, i32, i32, vp]
+        L.nbest_pack_bn_fp8.argtypes = [i64, i64]
+        L.nbest_pack_weights_fp8.argtypes = [vp, vp, vp, i32, i32, vp]
         L.nbest_gemm_fp8.argtypes = [C.POINTER(GemmFp8Args), vp]
         L.nbest_cast_bf16_to_fp8.argtypes = [vp, vp, i64, vp]
         L.nbest_wgrad_fp8_ws_bytes.restype = C.c_size_t
@@ -214,6 +217,20 @@ def pack_weight(W):
     dd = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(W.device)
     out = torch.empty_like(W)
     check(lib().nbest_pack_weights(ptr(W), ptr(out), ptr(dd), 1, (N // bn) * (K // 32), stream_ptr()), "pack_weights")
+    return out, bn
+
+
+def pack_weight_fp8(W8):
+    """W8 [N, K] e4m3 bytes -> (packed copy, tile width) for nbest_gemm_fp8_args::B_packed"""
+    N, K = W8.shape
+    bn = lib().nbest_pack_bn_fp8(N, K)
+    if bn == 0 or K % 64 or N % bn:
+        return None, 0
+    d = (MatrixDesc * 1)()
+    d[0].offset, d[0].rows, d[0].cols, d[0].tile_start, d[0].pad = 0, N, K, 0, bn
+    dd = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(W8.device)
+    out = torch.empty_like(W8)
+    check(lib().nbest_pack_weights_fp8(ptr(W8), ptr(out), ptr(dd), 1, (N // bn) * (K // 64), stream_ptr()), "pack_weights_fp8")
     return out, bn
 
 
@@ -305,7 +322,7 @@ def cast_fp8(x):
     return out
 
 
-def gemm_fp8(A8, W8, M, N, K, bias, out_scale=1.0, epilogue=EPI_BIAS, R=None, drop_p=0.0, seed=0, drop_stream=0, out=None):
+def gemm_fp8(A8, W8, M, N, K, bias, out_scale=1.0, epilogue=EPI_BIAS, R=None, drop_p=0.0, seed=0, drop_stream=0, out=None, B_packed=None, b_pack_bn=0):
     """C[M,N] (bf16) = epi((A8 . W8^T) * out_scale + bias), A8 / W8 e4m3 bytes; BIAS_GELU also returns (U 8-bit gelu', C8 fp8 copy)"""
     dev = A8.device
     if out is None:
@@ -321,6 +338,8 @@ def gemm_fp8(A8, W8, M, N, K, bias, out_scale=1.0, epilogue=EPI_BIAS, R=None, dr
         g.U, g.C8, g.ldu, g.ldc8 = U.data_ptr(), C8.data_ptr(), N, N
     if R is not None:
         g.R, g.ldr = R.data_ptr(), R.stride(0)
+    if B_packed is not None:
+        g.B_packed, g.b_pack_bn = B_packed.data_ptr(), b_pack_bn
     check(lib().nbest_gemm_fp8(C.byref(g), stream_ptr()), "gemm_fp8")
     return (out, U, C8) if epilogue == EPI_BIAS_GELU else out
 

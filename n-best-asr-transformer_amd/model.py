@@ -243,6 +243,9 @@ class NBestSTCModel(nn.Module):
         ok = getattr(a, "wpk", None) is not None and not a.w16t_stale
         d.wpk = a.wpk.data_ptr() if ok else None
         d.wpkt = a.wpkt.data_ptr() if ok else None
+        ok8 = getattr(a, "w8p", None) is not None
+        d.w8p = a.w8p.data_ptr() if ok8 else None
+        d.w8tp = a.w8tp.data_ptr() if ok8 else None
 
     def _set_fp8_backward(self, d):
         """descriptor fields of the fp8 backward; the same values in the forward and the backward of one step"""

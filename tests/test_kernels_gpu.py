@@ -512,6 +512,24 @@ def test_gemm_fp8_forward_epilogues(M, N, K):
     assert torch.equal(hb.cast_fp8(x).view(torch.float8_e4m3fn).float(), _e4m3(x.float().cpu()).float().to(DEV))     # RNE, like torch
 
 
+@pytest.mark.parametrize("N,K", [(2304, 768), (768, 768), (3072, 768), (768, 3072)])
+def test_gemm_fp8_packed_weights_identical(N, K):
+    """nbest_pack_weights_fp8 + nbest_gemm_fp8_args::B_packed: bit-identical to the unpacked call at the training size (256- and 128-column
+    tiles take the packed operand) and at a small M (where the other tile width may be chosen and the packed operand ignored)."""
+    g = torch.Generator().manual_seed(N + K)
+    W8 = _e4m3(torch.randn(N, K, generator=g) * 20).to(DEV).view(torch.uint8)
+    Wp, bn = hb.pack_weight_fp8(W8)
+    assert Wp is not None and bn in (128, 256) and not torch.equal(Wp, W8)
+    bias = rnd(N, seed=4)
+    for M in (32768 - 88, 300):
+        A8 = _e4m3(torch.randn(M, K, generator=g)).to(DEV).view(torch.uint8)
+        R = rnd(M, N, dtype=torch.bfloat16, seed=6)
+        for epi, kw in ((hb.EPI_BIAS, {}), (hb.EPI_BIAS_DROP_RES, dict(R=R))):
+            ref = hb.gemm_fp8(A8, W8, M, N, K, bias, 0.05, epilogue=epi, **kw)
+            got = hb.gemm_fp8(A8, W8, M, N, K, bias, 0.05, epilogue=epi, B_packed=Wp, b_pack_bn=bn, **kw)
+            assert torch.equal(got, ref), "packed e4m3 B differs: N=%d K=%d M=%d epi=%d" % (N, K, M, epi)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (768, 768, 1000), (2304, 768, 4096), (768, 3072, 5000)])
 def test_wgrad_fp8_transposed_reads(M, N, K):
     """fp8 weight gradient dW = dY8^T . X8 over K token rows (ragged K: zero-filled tail), both operands token-major e4m3 read
