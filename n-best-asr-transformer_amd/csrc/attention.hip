@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(
     // normalise (+ dropout) and round to bf16 at once: the probabilities are the A operand of the P.V MFMA (k order of an
     // accumulator tile, see acc_to_frag) - kept as packed bf16 they occupy half the registers of the fp32 scores
     bf16x8 pa[NKB][2];
-    if (DROP && (S & 1) == 0) {
+    if (DROP && drop.thr16 && (S & 1) == 0) {
       // registers (2j, 2j+1) hold keys (k, k+1) with k even: with S even they are one element pair of the counter
       // stream, so one hash decides both
       // counter of the pair = (row base + key) / 2 with an even row base: its product with the hash's odd constant splits into a
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float pv = sc[kb][r] * inv;
-          if (DROP) {
+          if (DROP && drop.thr16) {
             const int key = 32 * kb + crow(r, hh);
             const bool kp = nb_keep(drop, (uint32_t)((bh * S + qrow) * S + key));
             pv = kp ? pv * drop.scale : 0.f;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(
           }
           pa[kb][r >> 3][r & 7] = (bf16)pv;
         }
-        if (DROP && keep_out) {
+        if (DROP && keep_out && drop.thr16) {
           kw |= (uint32_t)__shfl_xor((int)kw, 32, 64);
           if (hh == 0 && qrow < Sp) keep_out[((int64_t)bh * NKB + kb) * Sp + qrow] = kw;
         }
