@@ -223,7 +223,7 @@ __device__ __forceinline__ void store_tile(char* img, int row0, const f32x16& o0
 // of 48.5 KiB - four workgroups per CU instead of three, with the registers capped at 128 for that (launch bounds).  The kernel
 // is bound by memory latency (0.8 MB in flight per workgroup, ~10 us each), not by arithmetic: residency is what it wants.
 template <int NKB, bool DROP>
-__global__ __launch_bounds__(256, (NKB <= 4 ? 4 : 1)) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(256, (NKB <= 4 ? (DROP ? 3 : 4) : 1)) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                             bf16* __restrict__ ctx, float* __restrict__ lse, int S, int heads,
                                                             int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8,
                                                             uint32_t* __restrict__ keep_out) {
