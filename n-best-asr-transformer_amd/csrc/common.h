@@ -157,11 +157,12 @@ __device__ __forceinline__ void st_stream_bf16x8(bf16* p, const float* v, bool n
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+template <int AUX = 2 /* nt */>
 __device__ __forceinline__ void nb_bstore_bf16x8(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, const float* v) {
   bf16x8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, byte_off, 0, 2 /* nt */);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, byte_off, 0, AUX);
 }
 __device__ __forceinline__ void nb_bstore8(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, uint32_t lo, uint32_t hi) {
   __builtin_amdgcn_raw_buffer_store_b64(u32x2{lo, hi}, rs, byte_off, 0, 2 /* nt */);

@@ -747,7 +747,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
           for (int j = 0; j < TNt; ++j) v[j] *= gd[j];
         }
-        if constexpr (TNt == 8) nb_bstore_bf16x8(rsC, voC + rr * svC, v);
+        // (experiment DIAG & 4096: the QKV projection - the step's only plain-bias GEMM - written WITHOUT the streaming hint, for its
+        // immediate reader, the attention forward)
+        if constexpr (TNt == 8) nb_bstore_bf16x8<(EPI == NBEST_EPI_BIAS && (DIAG & 4096)) ? 0 : 2>(rsC, voC + rr * svC, v);
         else if constexpr (TNt == 6) {
           bf16x2 o0 = {(bf16)v[0], (bf16)v[1]}, o1 = {(bf16)v[2], (bf16)v[3]}, o2 = {(bf16)v[4], (bf16)v[5]};
           __builtin_amdgcn_raw_buffer_store_b96(u32x3{__builtin_bit_cast(uint32_t, o0), __builtin_bit_cast(uint32_t, o1), __builtin_bit_cast(uint32_t, o2)},
