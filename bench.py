@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--no_dropout", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true", help="skip the in-step event timing (profiler passes)")
+    ap.add_argument("--shard_optimizer", default="auto", choices=["auto", "on", "off"],
+                    help="data parallel: BertAdam sharded over the ranks (auto: models over 200 M parameters - see DESIGN 6)")
     ap.add_argument("--no_packed_weights", action="store_true", help="A/B diagnostic: the GEMMs read the weight matrices row by row (round-2 behaviour)")
     a = ap.parse_args()
 
@@ -223,9 +225,13 @@ def main():
     batch["word_rows"] = torch.from_numpy(np.unique(np.concatenate([b[k].ravel() for k in ("ids", "tids") if k in b]))).to(dev)
     t_total = 100000
     distributed = dist.is_available() and dist.is_initialized()
-    # data parallel: the optimizer is sharded over the ranks (gradients reduced to the owner of each arena range, owners broadcast the
-    # bf16 compute copy: 0.75 x the bytes of the all-reduce, 1/N of the BertAdam traffic per GPU); a no-op for one process
-    optim = HipBertAdam(model, lr=3e-5, bert_lr=3e-5, warmup=0.1, t_total=t_total, shard=distributed)
+    # data parallel: the optimizer sharded over the ranks (gradients reduced to the owner of each arena range, owners broadcast the bf16
+    # compute copy: 0.75 x the bytes of the all-reduce, 1/N of the BertAdam traffic per GPU) where the replicated update is the larger
+    # cost - models over 200 M parameters (XLM-R); at bert-base the N sequential owner broadcasts after the update (21 MB each, not
+    # overlappable with anything) cost about what the 0.57 ms replicated update does, so the plain all-reduce path stays
+    n_params = sum(s.numel for s in model.arena.slots)
+    shard = distributed and (a.shard_optimizer == "on" or (a.shard_optimizer == "auto" and n_params > 200e6))
+    optim = HipBertAdam(model, lr=3e-5, bert_lr=3e-5, warmup=0.1, t_total=t_total, shard=shard)
     reducer = GradReducer(model.arena, owner_ranges=optim.owner_ranges) if distributed else None
 
     def step():

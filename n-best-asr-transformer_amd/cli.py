@@ -235,7 +235,8 @@ def main(argv=None):
         raise SystemExit("no training split at %s" % os.path.join(opt.dataroot, opt.train_file))
     t_total = (len(train) // opt.batchSize + 1) * opt.max_epoch            # n_best_asr_bert.py:556
     opt.optimizer = HipBertAdam(model, lr=opt.lr, bert_lr=opt.bert_lr, warmup=opt.warmup_proportion, t_total=t_total,
-                                shard=True)      # sharded over the data-parallel ranks (a no-op for one process / the fp8 mode)
+                                shard=sum(s.numel for s in model.arena.slots) > 200e6)   # data parallel: sharded over the ranks for the large
+                                                                                         # (XLM-R) models, replicated behind the all-reduce for BERT
     log = _Log(os.path.join(opt.exp_dir, "log.train"), rank, append=opt.resume and os.path.exists(os.path.join(opt.exp_dir, "last.pt")))
     t_start = time.time()
     log.info("Training starts at %s" % time.asctime(time.localtime(t_start)))
