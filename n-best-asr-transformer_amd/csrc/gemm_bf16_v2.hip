@@ -516,7 +516,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }
     {
       const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
-      if (younger >= 2) wait_vm<2 * NDMA>();
+      if (STAGES >= 5 && younger >= 3) wait_vm<3 * NDMA>();
+      else if (younger >= 2) wait_vm<2 * NDMA>();
       else if (younger == 1) wait_vm<NDMA>();
       else wait_vm<0>();
     }
@@ -547,7 +548,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       {
         // retire this wave's share of stage kt+1 (read by group 0 two slots from now)
         const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1;   // stages kt+1.. outstanding
-        if (c >= 3) wait_vm<2 * NDMA>();
+        if (STAGES >= 5 && c >= 4) wait_vm<3 * NDMA>();
+        else if (c >= 3) wait_vm<2 * NDMA>();
         else if (c == 2) wait_vm<NDMA>();
         else if (c == 1) wait_vm<0>();
       }
@@ -1133,6 +1135,10 @@ static bool persistent_enabled() {
   static const bool v = [] { const char* e = getenv("NBEST_PERSISTENT"); return e && *e == '1'; }();
   return v;
 }
+static bool stages5_enabled() {
+  static const bool v = [] { const char* e = getenv("NBEST_STAGES"); return e && *e == '5'; }();
+  return v;
+}
 static bool sym_enabled() {
   static const bool v = [] { const char* e = getenv("NBEST_SYM"); return e && *e == '1'; }();
   return v;
@@ -1153,6 +1159,7 @@ static int forced_tile() {
 #else
 static constexpr bool persistent_enabled() { return false; }
 static constexpr bool sym_enabled() { return false; }
+static constexpr bool stages5_enabled() { return false; }
 static constexpr int forced_tile() { return 0; }
 #endif
 
@@ -1352,7 +1359,12 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
   int rc, wave_rows = 2;   // wave rows per tile = partial rows of the fused column sums
   NB_CHECK(a->N % pl.bn == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld is not a multiple of the %d-column tile", (long long)a->N, pl.bn);
   if (pl.bm == 256 && pl.bn == 192) {
-    rc = launch2<256, 192, 4, 2, 4, false, false>(p, epi, grid, st); wave_rows = 4;
+    // ring depth: the operand delivery of these kernels is bound by bytes in flight against the LDS-DMA latency (3 stages of 28-32 KB
+    // against ~2 us); a fifth stage (all 160 KB of LDS at 256 x 256) pays at long K - FFN-down forward 162 -> 155 us, FFN-up dgrad 157 ->
+    // 154, QKV dgrad 122 -> 120 - and costs 1-2 % at K = 768, where the longer prologue of each tile weighs more (same-call A/B, twice)
+    if (a->K >= 2048 || stages5_enabled()) rc = launch2<256, 192, 4, 2, 5, false, false>(p, epi, grid, st);
+    else rc = launch2<256, 192, 4, 2, 4, false, false>(p, epi, grid, st);
+    wave_rows = 4;
   } else if (pl.bm == 128 && pl.bn == 256) {
     if (!a->trans_a && !a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<128, 256, 2, 4, 4, false, true>(p, epi, grid, st);
@@ -1380,7 +1392,8 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
       if (sym_enabled()) rc = launch2<256, 256, 4, 2, 4, false, false, true>(p, epi, grid, st);
       else
 #endif
-      rc = launch2<256, 256, 4, 2, 4, false, false>(p, epi, grid, st);
+      if (a->K >= 2048 || stages5_enabled()) rc = launch2<256, 256, 4, 2, 5, false, false>(p, epi, grid, st);
+      else rc = launch2<256, 256, 4, 2, 4, false, false>(p, epi, grid, st);
       wave_rows = 4;
     }
     else if (!a->trans_a && !a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, false>(p, epi, grid, st);
