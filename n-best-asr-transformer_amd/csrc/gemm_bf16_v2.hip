@@ -1398,6 +1398,7 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
     }
     else if (!a->trans_a && !a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, false>(p, epi, grid, st);
     else if (!a->trans_a && a->trans_b) rc = launch2<256, 256, 2, 4, 4, false, true>(p, epi, grid, st);
+    else if (stages5_enabled()) rc = launch2<256, 256, 2, 4, 5, true, true>(p, epi, grid, st);
     else rc = launch2<256, 256, 2, 4, 4, true, true>(p, epi, grid, st);
   } else if (pl.bm == 256) {
     if (!a->trans_b && epi != NBEST_EPI_F32_SPLITK) { rc = launch2<256, 128, 4, 1, 3, false, false>(p, epi, grid, st); wave_rows = 4; }
