@@ -40,6 +40,8 @@ KERNELS = [
     ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 124416, "weight gradient QKV (2304x768)", gf(3 * H, H, M), (M * 4 * H * 2 + 3 * H * H * 4) / 1e6),
     ("gemm_bf16_kernel<true, true, 6>", None, "weight gradient attention-out (768x768)", gf(H, H, M), (M * 2 * H * 2 + H * H * 4) / 1e6),
     # round 3: register-epilogue kernels (256 x 256 tiles as 4 x 2 waves; 256 x 192 tiles for the N = 768 shapes)
+    ("gemm2_kernel<256, 192, 4, 2, 5, false, false, 5>", None, "dgrad + residual: QKV (K 2304) | FFN-up (K 3072), N 768 (256x192 tiles, 5-stage ring)", (gf(M, H, 3 * H) + gf(M, H, F)) / 2, (M * (3 * H + F) / 2 * 2 + 2 * M * H * 2 + (3 * H + F) / 2 * H * 2) / 1e6),
+    ("gemm2_kernel<256, 192, 4, 2, 5, false, false, 3>", None, "forward FFN-down + bias + dropout + residual (K 3072; 256x192 tiles, 5-stage ring)", gf(M, H, F), (M * F * 2 + 2 * M * H * 2 + F * H * 2) / 1e6),
     ("gemm2_kernel<256, 192, 4, 2, 4, false, false, 5>", None, "dgrad + residual: QKV (K 2304) | FFN-up (K 3072), N 768 (256x192 tiles)", (gf(M, H, 3 * H) + gf(M, H, F)) / 2, (M * (3 * H + F) / 2 * 2 + 2 * M * H * 2 + (3 * H + F) / 2 * H * 2) / 1e6),
     ("gemm2_kernel<256, 192, 4, 2, 4, false, false, 3>", None, "forward bias+dropout+residual: attention-out (K 768) | FFN-down (K 3072) (256x192 tiles)", (gf(M, H, H) + gf(M, H, F)) / 2, (M * (H + F) / 2 * 2 + 2 * M * H * 2) / 1e6),
     ("gemm2_kernel<256, 192, 4, 2, 4, false, false, 0>", None, "dgrad attention-out (256x192 tiles)", gf(M, H, H), (2 * M * H * 2 + H * H * 2) / 1e6),
@@ -88,6 +90,8 @@ def main(path):
         if hit is None:
             continue
         label, flops, mb = hit
+        if "256, 192, 4, 2, 4, false, false, 3>" in name and float(r["launches_per_step"]) < 18:   # since the 5-stage ring took FFN-down: attention-out only
+            label, flops, mb = "forward attention-out + bias + dropout + residual (K 768; 256x192 tiles)", gf(M, H, H), (M * H * 2 + 2 * M * H * 2 + H * H * 2) / 1e6
         label = label.replace(" | ", " / ")
         us, ms, n = float(r["avg_us"]), float(r["ms_per_step"]), float(r["launches_per_step"])
         traffic = float(r["traffic_bytes_per_launch"]) / 1e6
