@@ -1189,7 +1189,7 @@ static Plan make_plan(const nbest_gemm_args* a) {
   }
   // 256 x 192 tiles (ping-pong, 4 x 2 waves of 64 x 96 columns): N = 768 gives 4 x (M / 256) tiles - 512 = exactly two rounds on the
   // 256 CUs at M = 32 768, where 256 x 256 tiles give 384 = one and a half (a quarter of the chip idle for half the kernel) and
-  // the 128 x 128 kernel three rounds of a structure that tops out near 1 PFLOP/s.  Chosen when its rounds are fuller (with a
+  // the 128 x 128 kernel three rounds of a structure that tops out near 1 PFLOP/s.  Chosen from one full round of tiles when its rounds are fuller (with a
   // handicap for the smaller tile: 24 instead of 32 MFMAs per barrier pair); plain / bias / residual epilogues only.
   // Measured in the step: N = 768 (256-wide tiles: 75 % full rounds) - on a par with the 128 x 128 kernel it replaces (112 / 148 us
   // for the forward / dgrad pairs against 114 / 146), 4-6 % faster in isolation; N = 2304 (90 % full rounds) - 127 us against 116-121
@@ -1202,7 +1202,11 @@ static Plan make_plan(const nbest_gemm_args* a) {
       auto eff = [](int64_t t) { return (double)t / (double)(((t + 255) / 256) * 256); };
       const double e256 = (a->N % 256 == 0) ? eff(rows * (a->N / 256)) : 0.0;
       const double ecur = (pl.bm == 256 && pl.bn == 256) ? e256 : (a->N % 256 == 0 ? e256 : 0.0);
-      if (ft == 5 || (t192 >= 512 && 0.85 * eff(t192) > ecur)) { pl.bm = 256; pl.bn = 192; }
+      int64_t t192_min = 256;   // one full round of tiles is enough (was two): M = 16 384 rows - configs[3] +2.6 %, a 128-utterance batch +4.8 %
+#ifdef NBEST_EXPERIMENTS
+      if (const char* e = getenv("NBEST_T192MIN")) t192_min = atoll(e);
+#endif
+      if (ft == 5 || (t192 >= t192_min && 0.85 * eff(t192) > ecur)) { pl.bm = 256; pl.bn = 192; }
     }
   }
   const int64_t tiles = ((a->M + pl.bm - 1) / pl.bm) * (a->N / pl.bn);
