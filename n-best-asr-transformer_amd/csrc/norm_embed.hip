@@ -794,7 +794,10 @@ int nbest_internal_layernorm_bwd8(const void* dy, const void* x, const float* st
   if (nblk > 512) nblk = 512;   // isolated, 256 and 512 blocks tie (32 us for 200 MB); inside the step 512 is faster (35 vs 44 us)
   int rpb = (int)((M + nblk - 1) / nblk);
   nblk = (int)((M + rpb - 1) / rpb);
-  constexpr int waves = 4;
+#ifndef NBEST_LN_WAVES
+#define NBEST_LN_WAVES 4
+#endif
+  constexpr int waves = NBEST_LN_WAVES;   // 8: measured in the step, see profiles/README.md
   float* part = (float*)ws;
   const size_t smem = (size_t)3 * H * sizeof(float);
   const int wb = dbias ? 1 : 0;
