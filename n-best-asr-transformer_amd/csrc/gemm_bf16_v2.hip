@@ -1081,6 +1081,138 @@ __global__ __launch_bounds__(512, 2) void gemm2p_kernel(GemmP2 p) {
   }
 }
 
+
+// ---- persistent ping-pong kernel with the REGISTER epilogue (experiment, NBEST_PERSISTENT=2): one workgroup per CU walks tiles
+// t = blockIdx, blockIdx + G, ...; the LDS ring runs on into the next tile (its first three stages are issued during the last three
+// LOAD slots of the current one), so neither the LDS-DMA latency of a tile's prologue nor the workgroup launch is exposed, and the
+// epilogue - registers and buffer stores only, no LDS - overlaps the landing of those stages.  k-contiguous operands, 256 x 256 tiles,
+// 4 x 2 waves of 64 x 128, epilogues NONE / BIAS / BIAS_GELU.  vmcnt bookkeeping: per tile and wave the stream is
+//   S0 S1 S2 (issued inside the previous tile) | NST epilogue stores of the previous tile | 2 bias loads | S3 S4 ...
+// and operations complete in order, so "stage kt+1 landed" allows 2 stages + NST + 2 in flight at kt < 2 and 2 stages afterwards.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm2d_kernel(GemmP2 p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int BM = 256, BN = 256, WN = 2, NT = 512, STAGES = 4;
+  constexpr int WTM = 64, WTN = 128, TMt = 4, TNt = 8;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int NDMA = 4;
+  constexpr bool kHasBias = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU);
+  constexpr int NST = TMt * 4 * (EPI == NBEST_EPI_BIAS_GELU ? 2 : 1);   // store wave-instructions per tile and wave (ragged tiles too: range-checked)
+  constexpr int NBIAS = kHasBias ? 2 : 0;
+  static_assert(EPI == NBEST_EPI_NONE || EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU, "no residual / GELU' input");
+  static_assert(2 * NDMA + NST + NBIAS <= 63, "vmcnt is a 6-bit counter");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+  const int G = gridDim.x, tiles = p.tiles_m * p.tiles_n;
+  const int nk = (int)(p.K / BK);
+  const bool b_packed = p.Bp != nullptr;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(b_packed ? (void*)p.Bp : (void*)p.B, 0, b_packed ? p.bp_bytes : p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
+  auto tile_coords = [&](int t, int& tm, int& tn) {
+    const int id = xcd_remap2(t, tiles);
+    nb_tile_coords(id, p.tiles_m, p.gn, tm, tn);
+  };
+  auto issue = [&](int gstage, int tm, int tn, int s) {   // stage s of tile (tm, tn) -> ring buffer gstage & 3
+    char* dst = lds + (gstage & 3) * STAGE;
+    stage_tile2<false, BM, NT, NB_AUX_A>(rsA, dst, (int64_t)tm * BM, (int64_t)s * BK, p.lda, tid);
+    if (b_packed) stage_tile_packed<BN, NT, NB_AUX_B>(rsB, dst + A_BYTES, (uint32_t)((tn * nk + s) * B_BYTES), tid);
+    else stage_tile2<false, BN, NT, NB_AUX_B, WTN>(rsB, dst + A_BYTES, (int64_t)tn * BN, (int64_t)s * BK, p.ldb, tid);
+  };
+  const int dg = lane >> 4, dc = lane & 15;
+  int t_cur = blockIdx.x, tm, tn;
+  tile_coords(t_cur, tm, tn);
+  int gs = 0;   // ring position of stage 0 of the current tile
+#pragma unroll
+  for (int s = 0; s < 3; ++s) issue(gs + s, tm, tn, s);
+  bool first = true;
+  while (true) {
+    const int t_next = t_cur + G;
+    const bool has_next = t_next < tiles;
+    int tmn = 0, tnn = 0;
+    if (has_next) tile_coords(t_next, tmn, tnn);
+    const int64_t dcol = (int64_t)tn * BN + wn * WTN + TNt * dc;
+    const int64_t drow0 = (int64_t)tm * BM + wm * WTM + 4 * dg;
+    f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    if (kHasBias) { b0 = global_load_f32x4_asm(p.bias + dcol); b1 = global_load_f32x4_asm(p.bias + dcol + 4); }
+    f32x4 acc[TMt][TNt];
+#pragma unroll
+    for (int i = 0; i < TMt; ++i)
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    if (first) wait_vm<2 * NDMA + NBIAS>();
+    else wait_vm<2 * NDMA + NST + NBIAS>();
+    __builtin_amdgcn_s_barrier();                 // stage 0 of this tile landed for everyone
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
+    bf16x8 af[TMt], bfr[TNt];
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---------------- LOAD slot ----------------
+      const int si = kt + 3;
+      if (si < nk) issue(gs + si, tm, tn, si);
+      else if (has_next) issue(gs + si, tmn, tnn, si - nk);
+      const char* cur = lds + ((gs + kt) & 3) * STAGE;
+#pragma unroll
+      for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<false, BN>(cur + A_BYTES, wn * WTN + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < TMt; ++i) af[i] = read_frag2<false, BM>(cur, wm * WTM + i * 16, lane);
+      {
+        const int c = has_next ? 3 : ((nk - 1 - kt < 3) ? nk - 1 - kt : 3);   // stages kt+1 .. outstanding
+        if (c >= 3) {
+          if (kt >= 2) wait_vm<2 * NDMA>();
+          else if (first) wait_vm<2 * NDMA + NBIAS>();
+          else wait_vm<2 * NDMA + NST + NBIAS>();
+        } else if (c == 2) wait_vm<NDMA>();    // (tail of the last tile; over-waits at kt < 2 when nk < 5: safe)
+        else wait_vm<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- MFMA slot ----------------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TMt; ++i)
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count: both groups are in step again
+    // ---- register epilogue (gemm2_kernel's, reduced to these epilogues): bias loads are older than stage 3, which has landed ----
+    if (kHasBias) asm volatile("" : "+v"(b0), "+v"(b1));
+    const float db[TNt] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    const uint32_t voC = (uint32_t)((drow0 * p.ldc + dcol) * 2), svC = (uint32_t)(2 * p.ldc);
+    const uint32_t voU = (uint32_t)(drow0 * p.ldu + dcol), svU = (uint32_t)p.ldu;
+#pragma unroll
+    for (int i = 0; i < TMt; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t rr = (uint32_t)(16 * i + e);
+        float v[TNt];
+#pragma unroll
+        for (int j = 0; j < TNt; ++j) v[j] = acc[i][j][e] + (kHasBias ? db[j] : 0.f);
+        if (EPI == NBEST_EPI_BIAS_GELU) {
+          float gp[TNt];
+#pragma unroll
+          for (int j = 0; j < TNt; j += 2) {
+            f32x2 h2, g2;
+            gelu_pair_fast(f32x2{v[j], v[j + 1]}, h2, g2);
+            gp[j] = g2[0]; gp[j + 1] = g2[1]; v[j] = h2[0]; v[j + 1] = h2[1];
+          }
+          nb_bstore8(rsU, voU + rr * svU, gd_pack4(gp), gd_pack4(gp + 4));
+        }
+        nb_bstore_bf16x8(rsC, voC + rr * svC, v);
+      }
+    }
+    if (!has_next) break;
+    t_cur = t_next; tm = tmn; tn = tnn; gs += nk; first = false;
+  }
+}
+
 #endif  // NBEST_EXPERIMENTS
 
 // rows >= m_split of the slabs' [M][N] image belong to the second output of a weight-gradient pair (C2, ldc2); m_split = M: none
@@ -1133,6 +1265,10 @@ struct Plan {
 #ifdef NBEST_EXPERIMENTS
 static bool persistent_enabled() {
   static const bool v = [] { const char* e = getenv("NBEST_PERSISTENT"); return e && *e == '1'; }();
+  return v;
+}
+static bool persistent_direct_enabled() {
+  static const bool v = [] { const char* e = getenv("NBEST_PERSISTENT"); return e && *e == '2'; }();
   return v;
 }
 static bool stages5_enabled() {
@@ -1388,6 +1524,21 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
 #undef LP
     NB_LAUNCH_CHECK();
     rc = NBEST_OK;
+#endif
+#ifdef NBEST_EXPERIMENTS
+  } else if (pl.bm == 256 && pl.bn == 256 && !a->trans_a && !a->trans_b && pl.splits == 1 && !p.colpart && a->K % BK == 0 &&
+             a->K >= 5 * BK && grid > 256 && (epi == NBEST_EPI_NONE || epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU) &&
+             persistent_direct_enabled()) {
+    constexpr int lds_bytes = 4 * 2 * 256 * BK * 2;
+#define LD(E)                                                                                              \
+  case E:                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)gemm2d_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    gemm2d_kernel<E><<<256, 512, lds_bytes, st>>>(p);                                                      \
+    break;
+    switch (epi) { LD(NBEST_EPI_NONE) LD(NBEST_EPI_BIAS) LD(NBEST_EPI_BIAS_GELU) default: break; }
+#undef LD
+    NB_LAUNCH_CHECK();
+    rc = NBEST_OK; wave_rows = 4;
 #endif
   } else if (pl.bm == 256 && pl.bn == 256) {
     // k-contiguous operands: 4 x 2 waves with 64 x 128 wave tiles (register epilogue: 16-byte stores, whole 128-byte lines)
