@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--no_dropout", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true", help="skip the in-step event timing (profiler passes)")
-    ap.add_argument("--shard_optimizer", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--shard_optimizer", default="off", choices=["auto", "on", "off"],
                     help="data parallel: BertAdam sharded over the ranks (auto: models over 200 M parameters - see DESIGN 6)")
     ap.add_argument("--no_packed_weights", action="store_true", help="A/B diagnostic: the GEMMs read the weight matrices row by row (round-2 behaviour)")
     a = ap.parse_args()
@@ -225,6 +225,7 @@ def main():
     batch["word_rows"] = torch.from_numpy(np.unique(np.concatenate([b[k].ravel() for k in ("ids", "tids") if k in b]))).to(dev)
     t_total = 100000
     distributed = dist.is_available() and dist.is_initialized()
+    dist_backend = dist.get_backend() if distributed else None     # "nccl" = RCCL; recorded in the JSON line
     # data parallel: the optimizer sharded over the ranks (gradients reduced to the owner of each arena range, owners broadcast the bf16
     # compute copy: 0.75 x the bytes of the all-reduce, 1/N of the BertAdam traffic per GPU) where the replicated update is the larger
     # cost - models over 200 M parameters (XLM-R); at bert-base the N sequential owner broadcasts after the update (21 MB each, not
@@ -300,6 +301,7 @@ def main():
                        "global_batch": a.batch * world, "seq_len": a.seq_len, "n_best": a.n_best, "parallelism": "dp%d" % world,
                        "add_l2_loss": bool(a.add_l2_loss)},
             **({"rehearsal": "N ranks on ONE GPU over gloo: code-path check, not a measurement"} if rehearsal else {}),
+            "dist_backend": dist_backend,
             "flops_per_utterance": fpu,
             "step_mfma_frac": round(utt * fpu / 1e12 / ((PEAK_FP8_TFLOPS if a.dtype == "fp8w" else PEAK_BF16_TFLOPS) * world), 4),
             "last_loss_per_utt": round(loss / a.batch, 4),

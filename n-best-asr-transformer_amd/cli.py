@@ -102,6 +102,9 @@ def parse_arguments(argv=None):
     g.add_argument("--vocab", default=None, help="WordPiece vocabulary: vocab.txt (one token per line) or a JSON list")
     g.add_argument("--label_space", default=None, help="JSON with top2bottom / idx2label instead of memory.pt")
     g.add_argument("--encoder_layers", type=int, default=None, help="override the number of encoder layers (smoke runs)")
+    g.add_argument("--shard_optimizer", default="off", choices=["on", "off"],
+                   help="data parallel only: BertAdam sharded over the ranks (reduce-to-owner + owner broadcasts, DESIGN 6) instead of "
+                        "replicated behind the all-reduce.  Opt-in: the path has not run over RCCL on more than one GPU yet")
     opt = ap.parse_args(argv)
     if opt.optim_choice != "bertadam":
         ap.error("only --optim_choice bertadam is built (the shipped script's choice)")
@@ -235,8 +238,7 @@ def main(argv=None):
         raise SystemExit("no training split at %s" % os.path.join(opt.dataroot, opt.train_file))
     t_total = (len(train) // opt.batchSize + 1) * opt.max_epoch            # n_best_asr_bert.py:556
     opt.optimizer = HipBertAdam(model, lr=opt.lr, bert_lr=opt.bert_lr, warmup=opt.warmup_proportion, t_total=t_total,
-                                shard=sum(s.numel for s in model.arena.slots) > 200e6)   # data parallel: sharded over the ranks for the large
-                                                                                         # (XLM-R) models, replicated behind the all-reduce for BERT
+                                shard=opt.shard_optimizer == "on")
     log = _Log(os.path.join(opt.exp_dir, "log.train"), rank, append=opt.resume and os.path.exists(os.path.join(opt.exp_dir, "last.pt")))
     t_start = time.time()
     log.info("Training starts at %s" % time.asctime(time.localtime(t_start)))
@@ -272,15 +274,20 @@ def main(argv=None):
         tef, te_acc = res.get("test", (0.0, 0.0))
         if vf > best["vf"]:
             best.update(epoch=ep, vf=vf, tef=tef, v_acc=v_acc, te_acc=te_acc)
+            # sharded optimizer: the fp32 master is current only on each range's owner.  gather_master is a sequence of
+            # collectives: EVERY rank runs it (vf is the all-reduced F1, so every rank takes this branch together); only
+            # the file write is rank 0's
+            opt.optimizer.gather_master(moments=False)
             if rank == 0:
-                opt.optimizer.gather_master(moments=False)      # sharded optimizer: the fp32 master is current only on each range's owner
                 model.save_model(os.path.join(opt.exp_dir, "model.pt"))
             log.info("NEW BEST:\tEpoch: %02d\tvalid F1/Acc: %.2f/%.2f\ttest F1/Acc: %.2f/%.2f" % (ep, vf, v_acc, tef, te_acc))
-        if rank == 0 and opt.resume:
-            torch.save(dict(model={k: v.detach().cpu() for k, v in model.state_dict().items()},
-                            optimizer=opt.optimizer.state_dict(), best=best, epoch=ep, dropout_step=model.step_counter),
-                       last + ".tmp")
-            os.replace(last + ".tmp", last)
+        if opt.resume:
+            opt.optimizer.gather_master()           # all ranks (collectives); master and moments are whole everywhere afterwards
+            if rank == 0:                           # ... so the state dicts are built AFTER the gather, on rank 0 only
+                torch.save(dict(model={k: v.detach().cpu() for k, v in model.state_dict().items()},
+                                optimizer=opt.optimizer.state_dict(gather=False), best=best, epoch=ep, dropout_step=model.step_counter),
+                           last + ".tmp")
+                os.replace(last + ".tmp", last)
         if opt.stop_after_epoch is not None and ep >= opt.stop_after_epoch:
             log.info("Stopping after epoch %02d as requested" % ep)
             return 0

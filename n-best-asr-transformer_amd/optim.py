@@ -173,10 +173,13 @@ class HipBertAdam:
         self.step_main()
         self.step_embeddings()
 
-    def state_dict(self):
+    def state_dict(self, gather=True):
         """per-parameter ``next_m`` / ``next_v`` keyed by parameter name plus the shared step count — the content of
-        the reference optimizer's ``state[p]`` (optimization.py:256-262,300), independent of the arena layout"""
-        self.gather_master()
+        the reference optimizer's ``state[p]`` (optimization.py:256-262,300), independent of the arena layout.
+        Sharded mode: ``gather_master`` is a COLLECTIVE - either every rank calls ``state_dict()``, or every rank calls
+        ``gather_master()`` and the one rank that writes the checkpoint calls ``state_dict(gather=False)``."""
+        if gather:
+            self.gather_master()
         a = self.arena
         return dict(step=self.step_count, t_total=self.t_total, warmup=self.warmup,
                     state={s.name: dict(next_m=a.view(a.m, s.name).detach().cpu().clone(),

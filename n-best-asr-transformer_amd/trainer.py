@@ -42,6 +42,9 @@ def init_distributed(backend=None):
     # bucketed all-reduce, barrier) is the same code at every N and can be exercised on a 1-GPU box
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None and os.environ.get("NBEST_DP_REHEARSAL") == "1":
+        # one-GPU rehearsal of the multi-rank code path (tests): every rank on cuda:0, gloo as the transport
+        backend, local = "gloo", 0
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":

@@ -142,3 +142,53 @@ def test_cli_xlm_roberta_with_local_sentencepiece(tmp_path):
     assert "[Train]\tEpoch: 00" in log and "[Valid]\tEpoch: 00" in log and "nan" not in log.lower()
     lines = open(os.path.join(d, "valid.iter0")).read().strip("\n").split("\n")
     assert len(lines) == 24
+
+
+def test_cli_two_ranks_sharded_optimizer_saves_and_resumes(tmp_path):
+    """with the sharded optimizer, `gather_master` is a sequence of collectives - the best-model save and the
+    --resume checkpoint must run it on EVERY rank (round 3 called it under `if rank == 0`, which hangs the first new-best epoch).
+    Two ranks on cuda:0 over gloo (NBEST_DP_REHEARSAL) drive the CLI through torch.distributed.run with --shard_optimizer on:
+    epoch 0 writes last.pt (and model.pt on a new best), the second invocation resumes and finishes epoch 1.  The checkpoint's fp32
+    master must be whole: every tensor of last.pt equals the bf16 compute copy the ranks agree on, to bf16 rounding."""
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    import nbest_amd  # noqa: F401
+    from nbest_amd import cli
+    root = tmp_path / "data"
+    root.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "valid_200.txt"), root / "train")
+    shutil.copy(os.path.join(GOLDEN, "valid_head.txt"), root / "valid")
+    exp = str(tmp_path / "exp")
+    args = ["--dataset", "dstc2", "--dataroot", str(root), "--deviceId", "0", "--dropout", "0.3", "--bert_dropout", "0.1", "--lr", "1e-3",
+            "--bert_lr", "1e-4", "--batchSize", "16", "--max_epoch", "2", "--experiment", exp, "--add_segment_ids", "--n_best", "3",
+            "--label_space", os.path.join(GOLDEN, "label_space.json"), "--vocab", os.path.join(GOLDEN, "text_vocab.json"),
+            "--encoder_layers", "2", "--resume", "--shard_optimizer", "on"]
+    env = dict(os.environ, NBEST_DP_REHEARSAL="1", OMP_NUM_THREADS="4")
+    env.pop("RANK", None)
+
+    def run(extra, port):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "n_best_asr_bert.py")] + args + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+
+    run(["--stop_after_epoch", "0"], 29711)
+    d = cli.exp_dir(cli.parse_arguments(args))
+    ck0 = torch.load(os.path.join(d, "last.pt"), weights_only=True)
+    assert ck0["epoch"] == 0 and ck0["optimizer"]["step"] == 13
+    # a stale master outside rank 0's range would still hold the initial weights: every layer tensor must have moved
+    moved = [k for k, v in ck0["model"].items() if "encoder.layer" in k and "weight" in k and "LayerNorm" not in k]
+    for k in moved:
+        m_ = ck0["optimizer"]["state"][k]["next_m"]
+        assert m_.abs().max().item() > 0, "moment of %s never updated: gather_master(moments) missed its owner" % k
+    run([], 29712)
+    ck1 = torch.load(os.path.join(d, "last.pt"), weights_only=True)
+    assert ck1["epoch"] == 1 and ck1["optimizer"]["step"] == 26
+    log = open(os.path.join(d, "log.train")).read()
+    assert "Resumed after epoch 00 (optimizer step 13)" in log and log.count("[Train]\tEpoch: ") == 2
+    changed = sum(int(not torch.equal(ck0["model"][k], ck1["model"][k])) for k in moved)
+    assert changed == len(moved), "%d of %d layer matrices did not change over epoch 1: stale master in the checkpoint" % (len(moved) - changed, len(moved))
+    if "NEW BEST" in log:
+        assert os.path.exists(os.path.join(d, "model.pt"))

@@ -220,3 +220,23 @@ def test_bench_multi_rank_code_path_rehearsal(world, model, batch):
     rec = json.loads(line)
     assert rec["n_gpus"] == world and rec["value"] > 0 and rec["scaling"] == "weak" and "rehearsal" in rec
     assert rec["roofline"]["achieved"] > 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--model", "xlm-roberta", "--shard_optimizer", "on", "--batch", "8"]])
+def test_rccl_branch_runs_at_world_one(extra):
+    """the RCCL branch itself - init_process_group("nccl", device_id=...), all_gather_into_tensor, the async
+    all_reduce / reduce buckets on the communicator's stream, the side-stream count copy, barrier and tear-down - executed on the
+    one-GPU box: a FRESH child under torch.distributed.run with one rank and WITHOUT the gloo rehearsal switch.  (World 1 cannot
+    show a wrong sum; it shows that every call the 8-GPU run makes exists, accepts these arguments on RCCL and completes.)"""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "NBEST_BENCH_REHEARSAL", "NBEST_DP_REHEARSAL"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29733", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no_cpu_baseline"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and "rehearsal" not in rec and rec["value"] > 0
+    assert rec["dist_backend"] == "nccl", rec
