@@ -223,6 +223,11 @@ def main():
     # rows of the word-embedding table this shard touches, built on the host like trainer.EncodedSplit does: under data
     # parallelism a 250 002-row table (XLM-R) exchanges these rows instead of all-reducing 768 MB (trainer.GradReducer)
     batch["word_rows"] = torch.from_numpy(np.unique(np.concatenate([b[k].ravel() for k in ("ids", "tids") if k in b]))).to(dev)
+    # ... and the tokens sorted by word id (stable): the index of the deterministic embedding backward, built by the data loader next
+    # to ids (trainer.EncodedSplit.host_batch does the same for real data); a pure function of ids, resident like them
+    for k, pk in (("ids", "tok_perm"), ("tids", "ttok_perm")):
+        if k in b:
+            batch[pk] = torch.from_numpy(np.argsort(b[k].ravel(), kind="stable").astype(np.int32)).to(dev)
     t_total = 100000
     distributed = dist.is_available() and dist.is_initialized()
     dist_backend = dist.get_backend() if distributed else None     # "nccl" = RCCL; recorded in the JSON line

@@ -52,16 +52,22 @@ int nbest_embed_ln_fwd(const int64_t* ids, const int64_t* seg, const int64_t* po
                        const void* type, const void* ptab, const float* gamma, const float* beta, void* out,
                        float* stats, int64_t M, int H, float eps, int dtype, float drop_p, uint64_t seed,
                        uint32_t drop_stream, nbest_stream_t stream);
-/* backward: LN backward on dout, then scatter-add into the fp32 table gradients (atomics).
- * Rows word_pad_id of dword and pos_pad_id of dptab receive nothing (nn.Embedding padding_idx;
- * pass -1 for "no padding row").  dword/dtype_tab/dptab are ACCUMULATED into (+=, the caller
- * zeroes them); dgamma/dbeta are overwritten unless accumulate.  M = B*S.  ws: >= nbest_embed_bwd_ws_bytes(M, H) bytes.                                                          */
-int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const int64_t* pos, const void* word,
+/* backward: LN backward on dout, then the sums into the fp32 table gradients - the index_add of the installed BertEmbeddings
+ * backward behind /root/reference/models/model.py:43-45 - WITHOUT float atomics: a segmented reduce over the tokens sorted by
+ * word id, every addition in a fixed order (bit-reproducible run to run).
+ *   perm [B*S] int32 (REQUIRED): token indices sorted by ids, ties in ascending token index (any STABLE argsort of ids; the
+ *        data loader builds it next to ids - nbest_amd/trainer.py EncodedSplit.host_batch, bench.py).
+ * Rows word_pad_id of dword and pos_pad_id of dptab receive nothing (nn.Embedding padding_idx; pass -1 for "no padding row").
+ * tables_accumulate == 0: the table rows the batch touches are OVERWRITTEN (the caller has zeroed the rest of dword / dptab /
+ * dtype_tab); != 0: they are added to.  dgamma / dbeta are overwritten unless accumulate.  Deterministic for inputs whose
+ * position ids are the same in every sequence up to padding rows and whose token types are 0 / 1 (BERT, the RoBERTa family);
+ * other rows fall back to float atomics on dptab / dtype_tab.  M = B*S < 2^31.  ws: >= nbest_embed_bwd_ws_bytes(M, H) bytes. */
+int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const int64_t* pos, const int32_t* perm, const void* word,
                        const void* type, const void* ptab, const float* gamma, const float* stats,
                        const void* dout, float* dword, float* dtype_tab, float* dptab, float* dgamma,
                        float* dbeta, int B, int S, int H, int n_types, int dtype, int64_t word_pad_id,
-                       int64_t pos_pad_id, int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream,
-                       void* ws, size_t ws_bytes, nbest_stream_t stream);
+                       int64_t pos_pad_id, int accumulate, int tables_accumulate, float drop_p, uint64_t seed,
+                       uint32_t drop_stream, void* ws, size_t ws_bytes, nbest_stream_t stream);
 size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H);
 
 /* Sparse exchange of word-embedding gradient rows between data-parallel ranks (new functionality: the reference is single-process,
@@ -422,6 +428,9 @@ typedef struct nbest_encoder_desc {
   /* optional (fp8w): w8 / w8t packed by nbest_pack_weights_fp8, at the arena's element offsets (bytes) */
   const void* w8p;
   const void* w8tp;
+  /* REQUIRED by nbest_encoder_backward(with_embeddings): token indices of THIS pass sorted by word id (stable), int32 [B*S], device
+   * memory - see nbest_embed_ln_bwd.  Set per call like `seed` (it belongs to the batch, not to the shape).                        */
+  const int32_t* word_perm;
 } nbest_encoder_desc;
 size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
 size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);

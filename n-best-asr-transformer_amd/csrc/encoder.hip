@@ -297,6 +297,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   RUN(check_desc(d));
   NB_CHECK(0 <= layer_begin && layer_begin <= layer_end && layer_end <= d->L, NBEST_ERR_ARG, "encoder_backward: bad layer range");
   NB_CHECK(wts && prm && grad && ids && pos && key_mask && act && dhidden && ws, NBEST_ERR_ARG, "encoder_backward: null pointer");
+  NB_CHECK(!with_embeddings || d->word_perm, NBEST_ERR_ARG, "encoder_backward: desc.word_perm (stable argsort of this pass's ids) is required");
   const ActLayout a = act_layout(d);
   const WsLayout w = ws_layout(d);
   NB_CHECK(act_bytes >= a.total, NBEST_ERR_WORKSPACE, "encoder_backward: activation stash too small");
@@ -437,9 +438,10 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     if (e == hipSuccess) e = hipMemsetAsync(G(d->off_type), 0, (size_t)d->n_types * H * sizeof(float), st);
     NB_CHECK(e == hipSuccess, NBEST_ERR_LAUNCH, "encoder_backward: memset failed: %s", hipGetErrorString(e));
   }
-  RUN(nbest_embed_ln_bwd(ids, seg, pos, P.W(d->off_word), P.W(d->off_type), P.W(d->off_pos), P.P(d->off_emb_ln_g),
+  NB_CHECK(d->word_perm, NBEST_ERR_ARG, "encoder_backward: desc.word_perm (stable argsort of this pass's ids) is required");
+  RUN(nbest_embed_ln_bwd(ids, seg, pos, d->word_perm, P.W(d->off_word), P.W(d->off_type), P.W(d->off_pos), P.P(d->off_emb_ln_g),
                          (const float*)(A + a.emb_stats), dA, G(d->off_word), G(d->off_type), G(d->off_pos), G(d->off_emb_ln_g),
-                         G(d->off_emb_ln_b), d->B, d->S, H, d->n_types, dt, d->word_pad_id, d->pos_pad_id, accumulate,
+                         G(d->off_emb_ln_b), d->B, d->S, H, d->n_types, dt, d->word_pad_id, d->pos_pad_id, accumulate, accumulate,
                          d->hidden_drop, d->seed, sb, W + w.emb, w.emb_bytes, stream));
   return NBEST_OK;
 }

@@ -9,6 +9,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef NBEST_EMB_TPC
+#define NBEST_EMB_TPC 16
+#endif
+
 namespace {
 
 constexpr int kMaxRowredBlocks = 512;
@@ -463,26 +467,97 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   }
 }
 
-// Embedding backward, ONE kernel: LayerNorm backward per row -> de (fp32, registers only); de is added atomically into the
-// word-table row of the token, and summed IN REGISTERS for the position table, the token-type rows 0 / 1 and the LayerNorm
-// parameter gradients.  Block (j, y) owns sequence position j for the samples b = y, y + Y, ...: every row it sees has the same
-// position key (pos[b * S + j] == pos[j]: BERT's arange; for the RoBERTa family the same except padding rows, whose key is the
-// padding row and carries no gradient), so the position gradient never leaves the registers until one atomic add per block and
-// column.  Rows with another key / token type >= 2 fall back to row atomics.  (Before: a second kernel re-read a 100 MB fp32 copy
-// of de to form the position / type sums - 135 us at 14 % of the HBM rate, on top of the 100 MB write.)
+// Embedding backward, deterministic (round 4; rounds 1-3 summed the word table with fp32 atomics: 150 us at the atomic rate and
+// a step that was not bit-reproducible).  LayerNorm backward per token gives de = o (fp32, registers only); three kernels:
+//   embed_bwd_pos_kernel   block (j, y) owns sequence position j for the samples b = y, y + Y, ...: every row it sees has the same
+//                          position key (pos[b * S + j] == pos[j]: BERT's arange; for the RoBERTa family the same except padding rows,
+//                          whose key is the padding row and carries no gradient), so the position / token-type 0, 1 / LayerNorm-parameter
+//                          sums stay in registers and leave as ONE partial row per block and quantity (summed by embed_bwd_finalize_kernel
+//                          in a fixed order).  Rows with another position key / token type >= 2 fall back to row atomics (no family of
+//                          the path produces them).
+//   embed_bwd_word_kernel  the word table as a SEGMENTED REDUCE over the tokens sorted by word id (`perm`: a stable argsort of ids,
+//                          built by the data loader next to ids): wave c owns `tpc` consecutive sorted tokens, recomputes o for each
+//                          and adds runs of equal id in registers, in sorted order.  A run that begins and ends inside the chunk is
+//                          stored straight into its table row (one plain 16-byte store per lane, no atomics, no memset of the touched
+//                          rows needed); a run that crosses a chunk boundary leaves a partial row (slot 0: the run began before the
+//                          chunk; slot 1: it began in the chunk and continues past it).
+//   embed_bwd_wordfix_kernel  one block per chunk; the chunk in which a boundary-crossing run BEGINS sums that run's partial rows in
+//                          chunk order (fixed tree: wave w takes every 4th row, the four wave sums are added in wave order) and stores
+//                          the table row.  Frequent ids ([SEP]: (n_best + 1) x B tokens) span up to M / tpc chunks.
+// Same additions in the same order on every run: the gradient is bit-reproducible.  Both token kernels recompute o (two reads of
+// dout and of the gathered table rows, 2 x 100 MB at B = 256, S = 128 - mostly out of the Infinity Cache the second time) instead of
+// writing it (100 MB fp32 out, 100 MB back in).
 template <typename T, int VPL>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
-                                                        const int64_t* __restrict__ pos, const T* __restrict__ word,
-                                                        const T* __restrict__ type, const T* __restrict__ ptab,
-                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                        const T* __restrict__ dout, float* __restrict__ dword,
-                                                        float* __restrict__ dtype_tab, float* __restrict__ dptab,
-                                                        float* __restrict__ part, int B, int S, int H, int n_types,
-                                                        int64_t word_pad_id, int64_t pos_pad_id, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];  // [5][H] column sums (dgamma, dbeta, position, type 0, type 1) | [waves][H] row restage
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, nvec = H >> 2;
+struct EmbTok {
+  typename Vec4<T>::raw_t w[VPL], t[VPL], p[VPL], d[VPL];
+  float mean, rstd;
+};
+// FULL: H == 256 VPL (every lane owns VPL whole chunks): no exec-mask guards, so a group of token loads is one straight run of
+// global_load instructions the compiler never has to wait on early
+template <typename T, int VPL, bool FULL>
+__device__ __forceinline__ void emb_tok_load(EmbTok<T, VPL>& r, int64_t row, int64_t id, int64_t sv, int64_t key, const T* __restrict__ word,
+                                             const T* __restrict__ type, const T* __restrict__ ptab, const float* __restrict__ stats,
+                                             const T* __restrict__ dout, int H, int lane, int nvec) {
+  const T* wr = word + id * H;
+  const T* tr = type + sv * H;
+  const T* pr = ptab + key * H;
+  const T* dr = dout + row * H;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    if (FULL || c < nvec) {
+      r.w[i] = Vec4<T>::raw_load(wr + 4 * c); r.t[i] = Vec4<T>::raw_load(tr + 4 * c);
+      r.p[i] = Vec4<T>::raw_load(pr + 4 * c); r.d[i] = Vec4<T>::raw_load(dr + 4 * c);
+    }
+  }
+  r.mean = stats[2 * row]; r.rstd = stats[2 * row + 1];
+}
+// o = d(embedding sum) of the token; d / xh = dropout-masked upstream gradient and the normalised row (LayerNorm-parameter sums)
+template <typename T, int VPL, bool FULL>
+__device__ __forceinline__ void emb_tok_grad(const EmbTok<T, VPL>& r, int64_t row, const f32x4* gm, f32x4* o, f32x4* d, f32x4* xh, int H,
+                                             int lane, int nvec, float invH, const DropCfg& drop) {
+  f32x4 g[VPL];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    if (FULL || c < nvec) {
+      const f32x4 e = (Vec4<T>::cvt(r.w[i]) + Vec4<T>::cvt(r.t[i])) + Vec4<T>::cvt(r.p[i]);
+      xh[i] = (e - r.mean) * r.rstd;
+      d[i] = Vec4<T>::cvt(r.d[i]);
+      if (drop.thr16) {
+        const uint32_t k = nb_keep4(drop, (uint32_t)(row * H + 4 * c));
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) d[i][e2] = (k >> e2 & 1) ? d[i][e2] * drop.scale : 0.f;
+      }
+      g[i] = d[i] * gm[i];
+      s1 += sum4(g[i]);
+      s2 += sum4(g[i] * xh[i]);
+    } else {
+      xh[i] = g[i] = d[i] = f32x4{0, 0, 0, 0};
+    }
+  }
+  wave_sum2(s1, s2);
+  s1 *= invH; s2 *= invH;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) o[i] = (g[i] - s1 - xh[i] * s2) * r.rstd;
+}
+constexpr int kEmbGroupWord = 4, kEmbGroupPos = 2;   // tokens whose rows a wave has in flight at once (the position kernel carries five accumulator rows)
+
+template <typename T, int VPL, bool FULL>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ seg,
+                                                            const int64_t* __restrict__ pos, const T* __restrict__ word,
+                                                            const T* __restrict__ type, const T* __restrict__ ptab,
+                                                            const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                            const T* __restrict__ dout, float* __restrict__ dtype_tab,
+                                                            float* __restrict__ dptab, float* __restrict__ part, int* __restrict__ fixlist,
+                                                            int B, int S, int H, int64_t pos_pad_id, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [5][H] column sums (dgamma, dbeta, position, type 0, type 1)
+  // (readfirstlane: the wave index is uniform, but only this tells the compiler - otherwise every token index below is a
+  // "divergent" value and each readlane becomes a waterfall loop)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6, nvec = H >> 2;
   const float invH = 1.0f / (float)H;
-  float* rowbuf = acc + 5 * H + wave * H;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fixlist[0] = 0;   // work list of embed_bwd_word_kernel (launched next)
   for (int i = threadIdx.x; i < 5 * H; i += blockDim.x) acc[i] = 0.f;
   __syncthreads();
   f32x4 ag[VPL], ab[VPL], gm[VPL], ap[VPL], t0[VPL], t1[VPL];
@@ -494,68 +569,58 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   }
   const int j = blockIdx.x;
   const int64_t key0 = pos[j];
-  for (int b = blockIdx.y + gridDim.y * wave; b < B; b += gridDim.y * wpb) {
-    const int64_t row = (int64_t)b * S + j;
-    const int64_t id = ids[row], key = pos[row], sv = seg ? seg[row] : 0;
-    const T* wr = word + id * H;
-    const T* tr = type + sv * H;
-    const T* pr = ptab + key * H;
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    f32x4 xh[VPL], g[VPL], d[VPL];
-    float s1 = 0.f, s2 = 0.f;
+  const int bstep = gridDim.y * wpb, b0 = blockIdx.y + gridDim.y * wave;
+  // this wave's tokens b0, b0 + bstep, ...: indices of up to 64 of them at a time, one per lane (no dependent scalar load per token)
+  for (int base = b0; base < B; base += 64 * bstep) {
+    const int bl = base + lane * bstep;
+    const int64_t lrow = (int64_t)(bl < B ? bl : b0) * S + j;
+    const int64_t lid = ids[lrow], lkey = pos[lrow], lsv = seg ? seg[lrow] : 0;
+    int n = (B - base + bstep - 1) / bstep;
+    if (n > 64) n = 64;
+    auto bc = [&](int64_t v, int l) -> int64_t {
+      const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)v >> 32), l);
+      return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    // groups of kEmbGroupPos tokens: all their rows are requested before the first is reduced
+    for (int g0 = 0; g0 < n; g0 += kEmbGroupPos) {
+      EmbTok<T, VPL> r[kEmbGroupPos];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        f32x4 e = (Vec4<T>::load(wr + 4 * c) + Vec4<T>::load(tr + 4 * c)) + Vec4<T>::load(pr + 4 * c);
-        xh[i] = (e - mean) * rstd;
-        d[i] = Vec4<T>::load(dout + row * H + 4 * c);
-        if (drop.thr16) {
-          const uint32_t k = nb_keep4(drop, (uint32_t)(row * H + 4 * c));
+      for (int u = 0; u < kEmbGroupPos; ++u) {
+        const int k = (g0 + u < n) ? g0 + u : n - 1;
+        emb_tok_load<T, VPL, FULL>(r[u], bc(lrow, k), bc(lid, k), bc(lsv, k), bc(lkey, k), word, type, ptab, stats, dout, H, lane, nvec);
+      }
 #pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) d[i][e2] = (k >> e2 & 1) ? d[i][e2] * drop.scale : 0.f;
+      for (int u = 0; u < kEmbGroupPos; ++u) {
+        const int k = g0 + u;
+        if (k >= n) break;
+        const int64_t row = bc(lrow, k), key = bc(lkey, k), sv = bc(lsv, k);
+        f32x4 o[VPL], d[VPL], xh[VPL];
+        emb_tok_grad<T, VPL, FULL>(r[u], row, gm, o, d, xh, H, lane, nvec, invH, drop);
+        const bool own_key = (key == key0), t_is0 = (sv == 0), t_is1 = (sv == 1);   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+          ag[i] += d[i] * xh[i];
+          ab[i] += d[i];
+          if (own_key) ap[i] += o[i];
+          if (t_is0) t0[i] += o[i];
+          if (t_is1) t1[i] += o[i];
         }
-        g[i] = d[i] * gm[i];
-        s1 += sum4(g[i]);
-        s2 += sum4(g[i] * xh[i]);
-      } else {
-        xh[i] = g[i] = d[i] = f32x4{0, 0, 0, 0};
-      }
-    }
-    s1 = wave_sum(s1) * invH;
-    s2 = wave_sum(s2) * invH;
-    const bool own_key = (key == key0), t_is0 = (sv == 0), t_is1 = (sv == 1);   // wave-uniform
+        if ((!own_key && key != pos_pad_id) || (!t_is0 && !t_is1)) {   // not reached by BERT / RoBERTa-family inputs (see above)
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        f32x4 o = (g[i] - s1 - xh[i] * s2) * rstd;
-        *(f32x4*)(rowbuf + 4 * c) = o;
-        ag[i] += d[i] * xh[i];
-        ab[i] += d[i];
-        if (own_key) ap[i] += o;
-        if (t_is0) t0[i] += o;
-        if (t_is1) t1[i] += o;
+          for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (!own_key && key != pos_pad_id) atomicAdd(dptab + key * H + 4 * c + e, o[i][e]);
+                if (!t_is0 && !t_is1) atomicAdd(dtype_tab + sv * H + 4 * c + e, o[i][e]);
+              }
+          }
+        }
       }
     }
-    // scatter-add with lane-contiguous columns: every atomic wave-instruction covers 256 contiguous bytes of one table
-    // row (the shape that runs at the full float-atomic rate)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (id != word_pad_id) {
-      float* dw = dword + id * H;
-      for (int col = lane; col < H; col += 64) atomicAdd(dw + col, rowbuf[col]);
-    }
-    if (!own_key && key != pos_pad_id) {
-      float* dp = dptab + key * H;
-      for (int col = lane; col < H; col += 64) atomicAdd(dp + col, rowbuf[col]);
-    }
-    if (!t_is0 && !t_is1) {
-      float* dtp = dtype_tab + sv * H;
-      for (int col = lane; col < H; col += 64) atomicAdd(dtp + col, rowbuf[col]);
-    }
-    asm volatile("" ::: "memory");
   }
-  for (int w = 0; w < wpb; ++w) {   // waves take turns (no LDS float atomics, see ln_bwd_kernel)
+  for (int w = 0; w < wpb; ++w) {   // waves take turns, in wave order (no LDS float atomics, see ln_bwd_kernel)
     if (wave == w) {
 #pragma unroll
       for (int i = 0; i < VPL; ++i) {
@@ -572,12 +637,192 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     __syncthreads();
   }
   const int nblk = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int i = threadIdx.x; i < H; i += blockDim.x) {
-    part[((int64_t)0 * nblk + bid) * H + i] = acc[i];
-    part[((int64_t)1 * nblk + bid) * H + i] = acc[H + i];
-    if (key0 != pos_pad_id) atomicAdd(dptab + key0 * H + i, acc[2 * H + i]);
-    atomicAdd(dtype_tab + i, acc[3 * H + i]);
-    if (n_types > 1) atomicAdd(dtype_tab + H + i, acc[4 * H + i]);
+  for (int i = threadIdx.x; i < H; i += blockDim.x)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) part[((int64_t)k * nblk + bid) * H + i] = acc[k * H + i];
+}
+
+// sums of the partial rows of embed_bwd_pos_kernel, fixed order.  grid (ceil(H / 32), 4 + ceil(S / 32)), block (32, 32):
+//   y = 0, 1, 2, 3: dgamma, dbeta, token-type rows 0 / 1 = sum over all S * Y blocks (32 row lanes + an LDS tree);
+//   y = 4 + g: thread row r owns position j = 32 g + r: position row pos[j] = sum over the Y blocks (j, 0), (j, 1), ...
+// `accum_ln` / `accum_tab`: add to what the outputs hold.
+__global__ __launch_bounds__(1024) void embed_bwd_finalize_kernel(const float* __restrict__ part, const int64_t* __restrict__ pos, int S, int Y,
+                                                                  int H, int n_types, int64_t pos_pad_id, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, float* __restrict__ dtype_tab,
+                                                                  float* __restrict__ dptab, int accum_ln, int accum_tab) {
+  __shared__ float sm[32][33];
+  const int nblk = S * Y, col = blockIdx.x * 32 + threadIdx.x, y = blockIdx.y;
+  if (y >= 4) {
+    const int j = (y - 4) * 32 + threadIdx.y;
+    if (j >= S || col >= H) return;
+    const int64_t key = pos[j];
+    if (key == pos_pad_id) return;
+    const float* p = part + ((int64_t)2 * nblk + j) * H + col;      // blocks (j, 0), (j, 1), ...: bid = yy * S + j
+    float s = 0.f;
+    for (int yy = 0; yy < Y; ++yy) s += p[(int64_t)yy * S * H];
+    float* o = dptab + key * H + col;
+    *o = accum_tab ? *o + s : s;
+    return;
+  }
+  float* outp = y == 0 ? dgamma : (y == 1 ? dbeta : (y == 2 ? dtype_tab : (n_types > 1 ? dtype_tab + H : nullptr)));
+  const float* p = part + (int64_t)(y < 2 ? y : y + 1) * nblk * H + col;
+  const int acc = y < 2 ? accum_ln : accum_tab;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < H && outp != nullptr) {
+    int b = threadIdx.y;
+    for (; b + 96 < nblk; b += 128) {
+      s0 += p[(int64_t)b * H]; s1 += p[(int64_t)(b + 32) * H]; s2 += p[(int64_t)(b + 64) * H]; s3 += p[(int64_t)(b + 96) * H];
+    }
+    for (; b < nblk; b += 32) s0 += p[(int64_t)b * H];
+  }
+  sm[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.y == 0 && col < H && outp != nullptr) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += sm[r][threadIdx.x];
+    outp[col] = acc ? outp[col] + s : s;
+  }
+}
+
+// sorted id of sorted position i (out of range: sentinels that equal no id and not each other)
+__device__ __forceinline__ int64_t emb_sid(const int32_t* __restrict__ perm, const int64_t* __restrict__ ids, int64_t i, int64_t M) {
+  return i < 0 ? -2 : (i >= M ? -3 : ids[perm[i]]);
+}
+
+template <typename T, int VPL, bool FULL>
+__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int32_t* __restrict__ perm, const int64_t* __restrict__ ids,
+                                                             const int64_t* __restrict__ seg, const int64_t* __restrict__ pos,
+                                                             const T* __restrict__ word, const T* __restrict__ type,
+                                                             const T* __restrict__ ptab, const float* __restrict__ gamma,
+                                                             const float* __restrict__ stats, const T* __restrict__ dout,
+                                                             float* __restrict__ dword, float* __restrict__ wpart, int* __restrict__ fixlist,
+                                                             int64_t M, int H, int tpc, int64_t word_pad_id, int accumulate, DropCfg drop) {
+  const int lane = threadIdx.x & 63, nvec = H >> 2;
+  const int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: see the pos kernel
+  const int64_t i0 = c * tpc;
+  if (i0 >= M) return;
+  const int64_t i1 = (i0 + tpc < M) ? i0 + tpc : M;
+  const float invH = 1.0f / (float)H;
+  // lane l holds sorted position i0 - 1 + l: the chunk's token rows and ids (tpc <= 62) plus the id before and after the chunk
+  const int n = (int)(i1 - i0);
+  const int64_t li = i0 - 1 + lane;
+  const bool lin = lane <= n + 1 && li >= 0 && li < M;
+  const int64_t lrow = lin ? perm[li] : 0;
+  const int64_t lid = lin ? ids[lrow] : (li < 0 ? -2 : -3);          // sentinels equal no id
+  const int64_t lsv = (seg && lin) ? seg[lrow] : 0;
+  const int64_t lkey = lin ? pos[lrow] : 0;
+  auto bc = [&](int64_t v, int l) -> int64_t {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+  };
+  if (bc(lid, 1) == word_pad_id && bc(lid, n) == word_pad_id) return;   // sorted: the whole chunk is padding (no gradient)
+  f32x4 gm[VPL], acc[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int cc = lane + 64 * i;
+    gm[i] = (cc < nvec) ? *(const f32x4*)(gamma + 4 * cc) : f32x4{0, 0, 0, 0};
+    acc[i] = f32x4{0, 0, 0, 0};
+  }
+  bool run_began_here = true;                                // does the running sum hold the FIRST token of its id?
+  int64_t run_id = -5;
+  for (int g0 = 1; g0 <= n; g0 += kEmbGroupWord) {               // groups of kEmbGroupWord tokens: every row requested before the first is reduced
+    EmbTok<T, VPL> r[kEmbGroupWord];
+#pragma unroll
+    for (int u = 0; u < kEmbGroupWord; ++u) {
+      const int k = (g0 + u <= n) ? g0 + u : n;
+      emb_tok_load<T, VPL, FULL>(r[u], bc(lrow, k), bc(lid, k), bc(lsv, k), bc(lkey, k), word, type, ptab, stats, dout, H, lane, nvec);
+    }
+#pragma unroll
+    for (int u = 0; u < kEmbGroupWord; ++u) {
+      const int k = g0 + u;
+      if (k > n) break;
+      const int64_t id = bc(lid, k), row = bc(lrow, k);
+      if (id == word_pad_id) continue;                       // padding rows carry no gradient
+      if (id != run_id) {                                    // a new run starts with this token
+        run_id = id;
+        run_began_here = (bc(lid, k - 1) != id);             // k = 1: compares with the id before the chunk
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) acc[i] = f32x4{0, 0, 0, 0};
+      }
+      f32x4 o[VPL], d[VPL], xh[VPL];
+      emb_tok_grad<T, VPL, FULL>(r[u], row, gm, o, d, xh, H, lane, nvec, invH, drop);
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) acc[i] += o[i];
+      const int64_t id_next = bc(lid, k + 1);                // k = n: the id after the chunk
+      if (id_next != id) {                                   // the run ends with this token
+        float* dst = run_began_here ? dword + id * H : wpart + (c * 2 + 0) * H;
+        const bool add = run_began_here && accumulate;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+          const int cc = lane + 64 * i;
+          if (FULL || cc < nvec) *(f32x4*)(dst + 4 * cc) = add ? *(const f32x4*)(dst + 4 * cc) + acc[i] : acc[i];
+        }
+      } else if (k == n) {                                   // the chunk ends inside the run
+        float* dst = wpart + (c * 2 + (run_began_here ? 1 : 0)) * H;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+          const int cc = lane + 64 * i;
+          if (FULL || cc < nvec) *(f32x4*)(dst + 4 * cc) = acc[i];
+        }
+        // the chunk in which a boundary-crossing run BEGINS owns its fix-up (order of the list: irrelevant - every entry is a
+        // different table row, and the additions inside a row are ordered by chunk)
+        if (run_began_here && lane == 0) fixlist[1 + atomicAdd(fixlist, 1)] = (int)c;
+      }
+    }
+  }
+}
+
+// Fix-up of the runs that cross chunk boundaries: a fixed grid of blocks walks embed_bwd_word_kernel's work list (chunks in
+// which such a run begins); the block adds the run's partial rows in chunk order and stores the table row.
+__global__ __launch_bounds__(256) void embed_bwd_wordfix_kernel(const int32_t* __restrict__ perm, const int64_t* __restrict__ ids,
+                                                                const float* __restrict__ wpart, const int* __restrict__ fixlist,
+                                                                float* __restrict__ dword, int64_t M, int H, int tpc, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];       // [4][H]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nvec = H >> 2;
+  int* first = (int*)sm;                                           // [4], before the row sums use the buffer
+  const int count = fixlist[0];
+  for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    const int64_t c = fixlist[1 + item];
+    const int64_t i1 = (c + 1) * tpc;                              // < M: the run continues past the chunk
+    const int64_t id = emb_sid(perm, ids, i1 - 1, M);
+    // chunks c + 1 .. ce continue the run (slot 0 each); the run ends in chunk ce = the first chunk q > c whose end is the end of
+    // the data or is followed by another id.  256 candidates are probed at once (a serial walk costs two dependent loads per
+    // chunk: 73 us for the (n_best + 1) x B [SEP] tokens of a batch).
+    int64_t ce = c + 1;
+    for (int64_t base = c + 1;; base += 256) {
+      const int64_t q = base + threadIdx.x;
+      const int64_t e1 = ((q + 1) * tpc < M) ? (q + 1) * tpc : M;
+      const bool ends = e1 >= M || emb_sid(perm, ids, e1, M) != id;
+      const unsigned long long m = __ballot(ends);
+      if (lane == 0) first[wave] = m ? (__ffsll((long long)m) - 1) + 64 * wave : 1 << 30;
+      __syncthreads();
+      const int f = min(min(first[0], first[1]), min(first[2], first[3]));
+      __syncthreads();
+      if (f < (1 << 30)) { ce = base + f; break; }
+    }
+    for (int cc = lane; cc < nvec; cc += 64) {
+      f32x4 s = {0, 0, 0, 0};
+      int64_t q = c + 1 + wave;
+      for (; q + 28 <= ce; q += 32) {                              // eight rows of this wave in flight, added in chunk order
+        f32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = *(const f32x4*)(wpart + ((q + 4 * u) * 2) * H + 4 * cc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u];
+      }
+      for (; q <= ce; q += 4) s += *(const f32x4*)(wpart + (q * 2) * H + 4 * cc);
+      *(f32x4*)(sm + wave * H + 4 * cc) = s;
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < nvec; cc += blockDim.x) {
+      f32x4 s = *(const f32x4*)(wpart + (c * 2 + 1) * H + 4 * cc);   // the part of the run inside its first chunk
+      s += *(const f32x4*)(sm + 4 * cc); s += *(const f32x4*)(sm + H + 4 * cc);
+      s += *(const f32x4*)(sm + 2 * H + 4 * cc); s += *(const f32x4*)(sm + 3 * H + 4 * cc);
+      float* dst = dword + id * H + 4 * cc;
+      *(f32x4*)dst = accumulate ? *(const f32x4*)dst + s : s;
+    }
+    __syncthreads();
   }
 }
 
@@ -742,9 +987,12 @@ extern "C" size_t nbest_rowred_ws_bytes(int64_t M, int64_t N) {
   if (b > kMaxLnBwdBlocks) b = kMaxLnBwdBlocks;
   return (size_t)3 * b * N * sizeof(float);
 }
+constexpr int kEmbTpc = NBEST_EMB_TPC;   // sorted tokens per wave of embed_bwd_word_kernel
 extern "C" size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H) {
-  (void)M;
-  return (size_t)3 * kMaxLnBwdBlocks * H * sizeof(float);   // partial rows of the LayerNorm-parameter gradients (<= kMaxLnBwdBlocks blocks)
+  // partial rows of embed_bwd_pos_kernel (<= kMaxLnBwdBlocks blocks x 5 quantities) | two partial rows per chunk of embed_bwd_word_kernel
+  // | the fix-up work list (a counter + one chunk id per entry)
+  const int64_t chunks = (M + kEmbTpc - 1) / kEmbTpc;
+  return (size_t)5 * kMaxLnBwdBlocks * H * sizeof(float) + (size_t)chunks * 2 * H * sizeof(float) + (size_t)(chunks + 4) * sizeof(int);
 }
 
 // y8 != NULL (bf16, H % 256 == 0, H <= 1024 only): also write the e4m3 copy of y that the next fp8 forward GEMM reads
@@ -882,16 +1130,19 @@ extern "C" int nbest_embed_ln_fwd(const int64_t* ids, const int64_t* seg, const 
   return NBEST_OK;
 }
 
-extern "C" int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const int64_t* pos, const void* word,
+extern "C" int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const int64_t* pos, const int32_t* perm, const void* word,
                                   const void* type, const void* ptab, const float* gamma, const float* stats,
                                   const void* dout, float* dword, float* dtype_tab, float* dptab, float* dgamma,
                                   float* dbeta, int B, int S, int H, int n_types, int dtype, int64_t word_pad_id,
-                                  int64_t pos_pad_id, int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream,
-                                  void* ws, size_t ws_bytes, nbest_stream_t stream) {
+                                  int64_t pos_pad_id, int accumulate, int tables_accumulate, float drop_p, uint64_t seed,
+                                  uint32_t drop_stream, void* ws, size_t ws_bytes, nbest_stream_t stream) {
   if (int e = check_h(H)) return e;
   const int64_t M = (int64_t)B * S;
   NB_CHECK(ids && pos && word && type && ptab && gamma && stats && dout && dword && dtype_tab && dptab && dgamma && dbeta && ws && M > 0,
            NBEST_ERR_ARG, "embed_ln_bwd: null pointer");
+  NB_CHECK(perm, NBEST_ERR_ARG, "embed_ln_bwd: perm (stable argsort of ids, int32 [B*S]) is required: the word-table gradient is a "
+                                "segmented reduce over the sorted tokens, not a scatter of atomics");
+  NB_CHECK(M < ((int64_t)1 << 31), NBEST_ERR_SHAPE, "embed_ln_bwd: B*S must fit int32 (perm)");
   NB_CHECK(ws_bytes >= nbest_embed_bwd_ws_bytes(M, H), NBEST_ERR_WORKSPACE, "embed_ln_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const DropCfg d = make_drop(drop_p, seed, drop_stream);
@@ -899,27 +1150,38 @@ extern "C" int nbest_embed_ln_bwd(const int64_t* ids, const int64_t* seg, const 
   int Y = kMaxLnBwdBlocks / S;
   if (Y > B) Y = B;
   if (Y < 1) Y = 1;
-  NB_CHECK((int64_t)S * Y <= kMaxLnBwdBlocks || Y == 1, NBEST_ERR_SHAPE, "embed_ln_bwd: bad grid");
-  NB_CHECK(S <= kMaxLnBwdBlocks, NBEST_ERR_SHAPE, "embed_ln_bwd: S = %d exceeds %d", S, kMaxLnBwdBlocks);
-  const int nblk = S * Y;
+  NB_CHECK((int64_t)S * Y <= kMaxLnBwdBlocks, NBEST_ERR_SHAPE, "embed_ln_bwd: S = %d exceeds %d", S, kMaxLnBwdBlocks);
   float* part = (float*)ws;
-  const size_t smem = (size_t)(5 + 4) * H * sizeof(float);
+  float* wpart = part + (size_t)5 * kMaxLnBwdBlocks * H;
+  const size_t smem = (size_t)5 * H * sizeof(float);
   const dim3 grid(S, Y);
-  if (dtype == NBEST_F32) {
-    DISPATCH_VPL(H, ((void)hipFuncSetAttribute((const void*)embed_bwd_kernel<float, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
-                     embed_bwd_kernel<float, VPL><<<grid, 256, smem, st>>>(ids, seg, pos, (const float*)word, (const float*)type,
-                                                                            (const float*)ptab, gamma, stats, (const float*)dout, dword,
-                                                                            dtype_tab, dptab, part, B, S, H, n_types, word_pad_id,
-                                                                            pos_pad_id, d)));
-  } else if (dtype == NBEST_BF16) {
-    DISPATCH_VPL(H, ((void)hipFuncSetAttribute((const void*)embed_bwd_kernel<bf16, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
-                     embed_bwd_kernel<bf16, VPL><<<grid, 256, smem, st>>>(ids, seg, pos, (const bf16*)word, (const bf16*)type,
-                                                                           (const bf16*)ptab, gamma, stats, (const bf16*)dout, dword,
-                                                                           dtype_tab, dptab, part, B, S, H, n_types, word_pad_id,
-                                                                           pos_pad_id, d)));
-  } else NB_CHECK(false, NBEST_ERR_DTYPE, "embed_ln_bwd: bad dtype %d", dtype);
+  const int64_t chunks = (M + kEmbTpc - 1) / kEmbTpc;
+  const unsigned wgrid = (unsigned)((chunks + 3) / 4);
+  int* fixlist = (int*)(wpart + (size_t)chunks * 2 * H);
+#define NB_EMB_BWD2(TT, FULL)                                                                                                   \
+  DISPATCH_VPL(H, ((void)hipFuncSetAttribute((const void*)embed_bwd_pos_kernel<TT, VPL, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem), \
+                   embed_bwd_pos_kernel<TT, VPL, FULL><<<grid, 256, smem, st>>>(ids, seg, pos, (const TT*)word, (const TT*)type, (const TT*)ptab, gamma, \
+                                                                                 stats, (const TT*)dout, dtype_tab, dptab, part, fixlist, B, S, H, pos_pad_id, d), \
+                   embed_bwd_word_kernel<TT, VPL, FULL><<<wgrid, 256, 0, st>>>(perm, ids, seg, pos, (const TT*)word, (const TT*)type, (const TT*)ptab, \
+                                                                                gamma, stats, (const TT*)dout, dword, wpart, fixlist, M, H,  \
+                                                                                kEmbTpc, word_pad_id, tables_accumulate, d)))
+#define NB_EMB_BWD(TT)                                   \
+  do {                                                   \
+    if (H % 256 == 0 && H <= 1024) NB_EMB_BWD2(TT, true); \
+    else NB_EMB_BWD2(TT, false);                         \
+  } while (0)
+  if (dtype == NBEST_F32) NB_EMB_BWD(float);
+  else if (dtype == NBEST_BF16) NB_EMB_BWD(bf16);
+  else NB_CHECK(false, NBEST_ERR_DTYPE, "embed_ln_bwd: bad dtype %d", dtype);
+#undef NB_EMB_BWD2
+#undef NB_EMB_BWD
   NB_LAUNCH_CHECK();
-  return finalize(part, nblk, H, dgamma, accumulate, dbeta, accumulate, nullptr, 0, st);
+  embed_bwd_wordfix_kernel<<<(unsigned)(chunks < 2048 ? chunks : 2048), 256, (size_t)4 * H * sizeof(float), st>>>(perm, ids, wpart, fixlist, dword, M, H,
+                                                                                                                    kEmbTpc, tables_accumulate);
+  embed_bwd_finalize_kernel<<<dim3((H + 31) / 32, 4 + (S + 31) / 32), dim3(32, 32), 0, st>>>(part, pos, S, Y, H, n_types, pos_pad_id, dgamma, dbeta,
+                                                                                             dtype_tab, dptab, accumulate, tables_accumulate);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
 }
 
 extern "C" int nbest_rows_gather(const float* table, const int64_t* rows, int64_t n_rows, int64_t cap, int64_t* ids_out,

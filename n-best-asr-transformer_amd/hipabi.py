@@ -75,7 +75,8 @@ class EncoderDesc(C.Structure):
                 ("wgrad_events_n", C.c_int32), ("wgrad_events", C.POINTER(C.c_void_p)),
                 ("w8", C.c_void_p), ("w8_inv_scale", C.c_void_p), ("w8t", C.c_void_p), ("gamax_prev", C.c_void_p),
                 ("gamax_new", C.c_void_p), ("fp8_bwd", C.c_int32), ("pad2", C.c_int32),
-                ("wpk", C.c_void_p), ("wpkt", C.c_void_p), ("w8p", C.c_void_p), ("w8tp", C.c_void_p)]
+                ("wpk", C.c_void_p), ("wpkt", C.c_void_p), ("w8p", C.c_void_p), ("w8tp", C.c_void_p),
+                ("word_perm", C.c_void_p)]
 
 
 _lib = None
@@ -111,7 +112,7 @@ def lib():
         L.nbest_encoder_wgrad_launches_per_layer.argtypes = [C.POINTER(EncoderDesc)]
         vp, i64, i32, f32, u64, u32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
         L.nbest_embed_ln_fwd.argtypes = [vp] * 10 + [i64, i32, f32, i32, f32, u64, u32, vp]
-        L.nbest_embed_ln_bwd.argtypes = [vp] * 14 + [i32, i32, i32, i32, i32, i64, i64, i32, f32, u64, u32, vp, sz, vp]
+        L.nbest_embed_ln_bwd.argtypes = [vp] * 15 + [i32, i32, i32, i32, i32, i64, i64, i32, i32, f32, u64, u32, vp, sz, vp]
         L.nbest_attention_fwd.argtypes = [vp] * 4 + [i32] * 5 + [f32, u64, u32, vp]
         L.nbest_attention_bwd.argtypes = [vp] * 7 + [i32, vp, sz] + [i32] * 5 + [f32, u64, u32, vp]
         L.nbest_attention_bwd_ws_bytes.argtypes = [i32, i32, i32]
@@ -440,9 +441,27 @@ def embed_ln_fwd(ids, seg, pos, word, type_tab, ptab, gamma, beta, eps, drop_p=0
     return out, stats
 
 
+def word_perm(ids):
+    """token indices sorted by word id, ties in token order (int32 [B*S]): the index the deterministic embedding backward
+    reduces over.  The data loaders build it on the host next to ids (trainer.EncodedSplit.host_batch, bench.py); this is the
+    device-side stand-in for callers that hand over bare id tensors (a stable sort on the current stream, no host sync)."""
+    return torch.sort(ids.reshape(-1), stable=True)[1].to(torch.int32)
+
+
 def embed_ln_bwd(ids, seg, pos, word, type_tab, ptab, gamma, stats, dout, B, S, word_pad_id=-1, pos_pad_id=-1, drop_p=0.0,
-                 seed=0, drop_stream=0):
+                 seed=0, drop_stream=0, perm=None, accumulate_into=None):
+    """accumulate_into = (dword, dtype_tab, dptab, dgamma, dbeta): add to these (tables_accumulate = accumulate = 1)"""
     H = word.shape[1]
+    if perm is None:
+        perm = word_perm(ids)
+    if accumulate_into is not None:
+        dword, dtype_tab, dptab, dg, db = accumulate_into
+        ws = _ws(lib().nbest_embed_bwd_ws_bytes(B * S, H), word.device)
+        check(lib().nbest_embed_ln_bwd(ptr(ids), ptr(seg), ptr(pos), ptr(perm), ptr(word), ptr(type_tab), ptr(ptab), ptr(gamma), ptr(stats),
+                                       ptr(dout), ptr(dword), ptr(dtype_tab), ptr(dptab), ptr(dg), ptr(db), B, S, H,
+                                       type_tab.shape[0], dtype_code(word.dtype), word_pad_id, pos_pad_id, 1, 1, drop_p, seed,
+                                       drop_stream, ptr(ws), ws.numel(), stream_ptr()), "embed_ln_bwd")
+        return dword, dtype_tab, dptab, dg, db
     dev = word.device
     dword = torch.zeros(word.shape, dtype=torch.float32, device=dev)
     dtype_tab = torch.zeros(type_tab.shape, dtype=torch.float32, device=dev)
@@ -450,9 +469,9 @@ def embed_ln_bwd(ids, seg, pos, word, type_tab, ptab, gamma, stats, dout, B, S, 
     dg = torch.zeros(H, dtype=torch.float32, device=dev)
     db = torch.zeros_like(dg)
     ws = _ws(lib().nbest_embed_bwd_ws_bytes(B * S, H), dev)
-    check(lib().nbest_embed_ln_bwd(ptr(ids), ptr(seg), ptr(pos), ptr(word), ptr(type_tab), ptr(ptab), ptr(gamma), ptr(stats),
+    check(lib().nbest_embed_ln_bwd(ptr(ids), ptr(seg), ptr(pos), ptr(perm), ptr(word), ptr(type_tab), ptr(ptab), ptr(gamma), ptr(stats),
                                    ptr(dout), ptr(dword), ptr(dtype_tab), ptr(dptab), ptr(dg), ptr(db), B, S, H,
-                                   type_tab.shape[0], dtype_code(word.dtype), word_pad_id, pos_pad_id, 0, drop_p, seed,
+                                   type_tab.shape[0], dtype_code(word.dtype), word_pad_id, pos_pad_id, 0, 0, drop_p, seed,
                                    drop_stream, ptr(ws), ws.numel(), stream_ptr()), "embed_ln_bwd")
     return dword, dtype_tab, dptab, dg, db
 

@@ -75,6 +75,7 @@ class _Pass:
         self.B, self.S = B, S
         self.hidden = None
         self.inputs = None
+        self.perm = None
 
 
 class NBestSTCModel(nn.Module):
@@ -207,8 +208,10 @@ class NBestSTCModel(nn.Module):
             rank = torch.distributed.get_rank()
         return self.seed + 7919 * self.step_counter + 15485863 * rank
 
-    def _encode(self, ps, ids, seg, train):
-        """one encoder pass through the C-ABI; returns hidden states [B*S, H] (a view into the stash)"""
+    def _encode(self, ps, ids, seg, train, perm=None):
+        """one encoder pass through the C-ABI; returns hidden states [B*S, H] (a view into the stash).
+        ``perm``: the pass's tokens sorted by word id (hipabi.word_perm; host-built by the data loaders) - only the backward
+        reads it; None = sorted on the device when a backward pass asks for it."""
         cfg = self.cfg
         ids = ids.contiguous()
         mask = (ids > 0).to(torch.uint8)               # quirk Q1: ids > 0 for EVERY family (models/model.py:43)
@@ -231,6 +234,7 @@ class NBestSTCModel(nn.Module):
                                                 hb.ptr(self._ws), self._ws_bytes, C.byref(out), hb.stream_ptr()),
                  "encoder_forward")
         ps.inputs = (ids, seg, pos, mask)
+        ps.perm = perm
         off = out.value - ps.act.data_ptr()
         M, H = ps.B * ps.S, cfg.hidden_size
         esz = 2 if self.compute_dtype == torch.bfloat16 else 4
@@ -264,6 +268,9 @@ class NBestSTCModel(nn.Module):
         self._set_packed(ps.desc)
         dh = hb.cls_grad_scatter(dcls, ps.B, ps.S, cfg.hidden_size, self.compute_dtype)
         ids, seg, pos, mask = ps.inputs
+        if ps.perm is None:
+            ps.perm = hb.word_perm(ids)
+        ps.desc.word_perm = ps.perm.data_ptr()
         L = cfg.num_hidden_layers
         bounds = chunks or [(0, L)]
         for (lo, hi) in sorted(bounds, reverse=True):
@@ -315,24 +322,26 @@ class NBestSTCModel(nn.Module):
     # ---- one training forward + backward (n_best_asr_bert.py:249-264) ---------------------------
     def forward_backward(self, input_ids, labels_f, seg_ids=None, trans_input_ids=None, trans_seg_ids=None,
                          add_l2_loss=False, mse_grad_scale=1.0, chunks=None, on_chunk_done=None, need_grad=True,
-                         accumulate=False, encoder_grad_scale=1.0):
+                         accumulate=False, encoder_grad_scale=1.0, tok_perm=None, trans_tok_perm=None):
         """Returns dict(top, bott, final, loss_parts[4] (device), asr_cls, trans_cls).  Gradients of the sum
         BCE(final) + BCE(top) + mean-CE (+ MSE) are left in ``arena.g``.  The transcript pass runs only
         when its output is used (--add_l2_loss); the reference computes and discards it otherwise (Q4).
         ``accumulate``: add to the gradients already in ``arena.g`` (gradient accumulation) instead of overwriting them.
         ``encoder_grad_scale``: multiplies the gradient entering the encoder (the CLS rows) - a loss-scaling knob; the tests use it to
-        make every gradient amax of the fp8 backward jump between two consecutive steps."""
+        make every gradient amax of the fp8 backward jump between two consecutive steps.
+        ``tok_perm`` / ``trans_tok_perm``: int32 [B*S] token indices sorted (stably) by word id, for the deterministic embedding
+        backward; the data loaders build them on the host next to the ids (None: sorted on the device)."""
         train = self.training
         B, S = input_ids.shape
         H = self.cfg.hidden_size
         pa = self._pass(B, S, 0)
-        ha = self._encode(pa, input_ids, seg_ids, train)
+        ha = self._encode(pa, input_ids, seg_ids, train, tok_perm)
         pt = ht = None
         St = 0
         if add_l2_loss and trans_input_ids is not None:
             St = trans_input_ids.shape[1]
             pt = self._pass(B, St, 1)
-            ht = self._encode(pt, trans_input_ids, trans_seg_ids, train)
+            ht = self._encode(pt, trans_input_ids, trans_seg_ids, train, trans_tok_perm)
         top, bott, fin, loss, dcls, _, _ = self._heads(ha, S, labels_f, need_grad=need_grad, train=train, accumulate=accumulate)
         dt = None
         if pt is not None:

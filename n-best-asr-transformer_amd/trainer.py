@@ -253,7 +253,8 @@ def train_step(model, optimizer, batch, add_l2_loss=False, add_segment_ids=True,
         reducer.set_step_tokens(batch["ids"], batch.get("tids") if add_l2_loss else None, rows=batch.get("word_rows"))
     out = model.forward_backward(batch["ids"], batch["labels"], seg_ids=seg, trans_input_ids=batch.get("tids"),
                                  trans_seg_ids=batch.get("tseg"), add_l2_loss=add_l2_loss, mse_grad_scale=mse_scale,
-                                 chunks=chunks, on_chunk_done=reducer.layers_ready if reducer is not None else None)
+                                 chunks=chunks, on_chunk_done=reducer.layers_ready if reducer is not None else None,
+                                 tok_perm=batch.get("tok_perm"), trans_tok_perm=batch.get("ttok_perm"))
     if reducer is not None:
         reducer.wait_layers()
         optimizer.step_main()             # runs while the embedding tables' all-reduce is still in flight
@@ -383,8 +384,15 @@ class EncodedSplit:
         y = self.y[torch.as_tensor(idx, dtype=torch.long)]
         # rows of the word-embedding table this batch touches (sparse gradient exchange under data parallelism)
         rows = torch.unique(torch.cat([ids.reshape(-1), tids.reshape(-1)]))
-        return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=y.pin_memory() if pin else y,
-                    word_rows=rows.pin_memory() if pin else rows)
+        # tokens sorted by word id, ties in token order: what the deterministic embedding backward reduces over (nbest_embed_ln_bwd)
+        perm, tperm = token_perm(ids), token_perm(tids)
+        p_ = (lambda t: t.pin_memory()) if pin else (lambda t: t)
+        return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=p_(y), word_rows=p_(rows), tok_perm=p_(perm), ttok_perm=p_(tperm))
+
+
+def token_perm(ids):
+    """host: int32 [B*S] token indices sorted by word id, ties in ascending token index (numpy's stable argsort)"""
+    return torch.from_numpy(np.argsort(ids.reshape(-1).numpy(), kind="stable").astype(np.int32))
 
 
 def encoded(data, opt, memory):
@@ -498,7 +506,7 @@ def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
             seg = b.get("seg") if opt.add_segment_ids else None
             out = model.forward_backward(b["ids"], b["labels"], seg_ids=seg, trans_input_ids=b.get("tids"), trans_seg_ids=b.get("tseg"),
                                          add_l2_loss=opt.add_l2_loss, mse_grad_scale=len(mine) / float(len(lists[bi])),
-                                         accumulate=not first)
+                                         accumulate=not first, tok_perm=b.get("tok_perm"), trans_tok_perm=b.get("ttok_perm"))
             group_rows.append(b["word_rows"])
             if last:
                 if reducer is not None:

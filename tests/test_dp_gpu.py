@@ -95,20 +95,18 @@ def _worker(rank, world, port, B, sparse, q, dtype_name="float32"):
             train_step(m2, opt2, shard(b), add_l2_loss=True, add_segment_ids=True, reducer=red2, global_batch=B)
         torch.cuda.synchronize()
         ws0 = m.arena.by_name["bert_encoder.embeddings.word_embeddings.weight"]
-        w_same = torch.equal(m2.arena.weights[ws0.offset + ws0.numel:], m.arena.weights[ws0.offset + ws0.numel:])   # what the next step would read
+        w_same = torch.equal(m2.arena.weights, m.arena.weights)   # what the next step would read (word table included)
         opt2.gather_master()
         torch.cuda.synchronize()
         got2 = m2.arena.p.clone()
-        # the word-embedding table's gradient is summed with fp32 atomics (order varies from run to run: two runs of the SAME
-        # optimizer differ there in the last bit), so bit-equality is asked of everything else: layers, heads, position / type tables
+        # (rounds 1-3 excluded the word table here: its gradient was summed with fp32 atomics.  Round 4: a segmented reduce in a
+        # fixed order - bit-equality is asked of the WHOLE arena, and of the control run.)
         ws_ = m.arena.by_name["bert_encoder.embeddings.word_embeddings.weight"]
-        rest = torch.ones(got.numel(), dtype=torch.bool, device=got.device)
-        rest[ws_.offset:ws_.offset + ws_.numel] = False
-        wd = (got2 - got)[~rest].abs()
-        sh = dict(equal=torch.equal(got2[rest], got[rest]), weights_equal=w_same, max=(got2 - got)[rest].abs().max().item(),
+        wd = (got2 - got)[ws_.offset:ws_.offset + ws_.numel].abs()
+        sh = dict(equal=torch.equal(got2, got), weights_equal=w_same, max=(got2 - got).abs().max().item(),
                   mean=(got2 - got).abs().mean().item(), word_max=wd.max().item(), word_mean=wd.mean().item(),
-                  m_equal=torch.equal(m2.arena.m[rest], m.arena.m[rest]), owned=[r_ for r_ in opt2.owner_ranges[rank]],
-                  ctrl_equal=torch.equal(gotc[rest], got[rest]), ctrl_max=(gotc - got)[rest].abs().max().item())
+                  m_equal=torch.equal(m2.arena.m, m.arena.m), owned=[r_ for r_ in opt2.owner_ranges[rank]],
+                  ctrl_equal=torch.equal(gotc, got), ctrl_max=(gotc - got).abs().max().item())
         g2h = got2.cpu()
         all2 = [torch.zeros_like(g2h) for _ in range(world)]
         dist.all_gather(all2, g2h)
@@ -182,7 +180,7 @@ def test_dp_step_equals_single_process(world, B, sparse, dtype_name):
         for name, ge, mx, mean, share in sorted(r0["rows"], key=lambda t: -t[2])[:12]:
             f.write("  %-64s %10.2e %10.2e %10.2e %.2e\n" % (name[-64:], ge, mx, mean, share))
         sh = r0["sharded"]
-        f.write("  sharded optimizer vs replicated (word table aside: its gradient is summed with atomics): parameters bit-equal %s (max |d| %.2e), "
+        f.write("  sharded optimizer vs replicated (whole arena, word table included): parameters bit-equal %s (max |d| %.2e), "
                 "compute copy bit-equal %s, moments bit-equal %s, replicas bit-identical %s; word table max |d| %.2e mean %.2e; rank 0 owns %s\n" % (
                     sh["equal"], sh["max"], sh["weights_equal"], sh["m_equal"], all(res[r]["sharded"]["replicas_same"] for r in range(world)),
                     sh["word_max"], sh["word_mean"], sh["owned"]))
@@ -190,10 +188,11 @@ def test_dp_step_equals_single_process(world, B, sparse, dtype_name):
     for r in range(world):
         sh = res[r]["sharded"]
         assert sh["replicas_same"], "sharded replicas diverged"
-        if world == 2 and sh["ctrl_equal"]:
-            assert sh["equal"] and sh["weights_equal"], ("sharded optimizer differs from the replicated one", sh)
-        else:                              # no tighter than two runs of the replicated path agree with each other
-            assert sh["mean"] < 2e-6 and sh["max"] <= max(10 * sh["ctrl_max"], 1e-4), sh
+        assert sh["ctrl_equal"], ("the replicated data-parallel step is not bit-reproducible run to run", sh)
+        if world == 2:                     # a + b is the same number whichever collective forms it
+            assert sh["equal"] and sh["weights_equal"] and sh["m_equal"], ("sharded optimizer differs from the replicated one", sh)
+        else:                              # world 3: reduce-to-owner and all-reduce may add the three terms in different orders
+            assert sh["mean"] < 2e-6 and sh["max"] <= 1e-4, sh
         assert res[r]["same"], "replicas diverged"
         if dtype_name != "float32":
             continue                       # the single-process comparison below carries fp32 bars

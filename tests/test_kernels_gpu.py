@@ -266,6 +266,66 @@ def test_embed_fwd_bwd(dtype):
     assert dword[0].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("dtype,H,roberta", [(torch.float32, 768, False), (torch.bfloat16, 768, True), (torch.bfloat16, 1024, False)])
+def test_embed_bwd_segmented_reduce(dtype, H, roberta):
+    """The word-table gradient is a segmented reduce over the tokens sorted by id (the index_add of the installed
+    BertEmbeddings backward behind /root/reference/models/model.py:43-45, without atomics).  Exercised here: ids that occur once,
+    a few times, in EVERY chunk of the sorted order ([SEP]-like: runs spanning dozens of chunks, so the partial-row fix-up sums
+    them), runs that end exactly at chunk boundaries, the padding row, the RoBERTa position rule (padding rows keyed to the padding
+    position: no gradient), accumulation into existing tables, a host-built permutation against the device-side one - and that two
+    runs give the SAME BITS in every output."""
+    B, S, V = 37, 53, 400
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(4, V, (B, S), generator=g)
+    ids[:, 0] = 2                                            # [CLS]-like: B tokens of one id
+    ids[:, 7::9] = 3                                         # [SEP]-like: ~6 per row -> one run of ~220 tokens = ~28 chunks of 8
+    for b in range(B):
+        ids[b, S - (b % 11):] = 1                            # ragged right padding (id 1 = padding_idx: no gradient)
+    ids[5, 10:18] = 77                                       # 8 equal tokens in a row: a run that can sit exactly on a chunk
+    ids = ids.to(DEV)
+    seg = (torch.arange(S)[None, :] > 12).long().expand(B, S).contiguous().to(DEV)
+    if roberta:                                              # model.position_ids_for: cumsum(ids != pad) * (ids != pad) + pad
+        nonpad = ids.ne(1).long()
+        pos = (torch.cumsum(nonpad, dim=1) * nonpad + 1).contiguous()
+        seg = torch.zeros_like(seg)
+        n_types, pos_pad = 1, 1
+    else:
+        pos = torch.arange(S)[None, :].expand(B, S).contiguous().to(DEV)
+        n_types, pos_pad = 2, -1
+    word, tt, pt = rnd(V, H, dtype=dtype, s=0.5, seed=61), rnd(n_types, H, dtype=dtype, s=0.5, seed=62), rnd(S + 2, H, dtype=dtype, s=0.5, seed=63)
+    gam, bet = 1 + 0.1 * rnd(H, seed=64), 0.1 * rnd(H, seed=65)
+    out, stats = hb.embed_ln_fwd(ids, seg, pos, word, tt, pt, gam, bet, 1e-5)
+    wr, tr, pr = (t.float().clone().requires_grad_(True) for t in (word, tt, pt))
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    e = torch.nn.functional.embedding(ids, wr, padding_idx=1) + tr[seg] + torch.nn.functional.embedding(pos, pr, padding_idx=1 if roberta else None)
+    ref = torch.nn.functional.layer_norm(e, (H,), gr, br, 1e-5).reshape(B * S, H)
+    dout = rnd(B * S, H, dtype=dtype, seed=66)
+    ref.backward(dout.float())
+    tol = 5 * tol_of(dtype)
+    host_perm = torch.from_numpy(np.argsort(ids.cpu().numpy().ravel(), kind="stable").astype(np.int32)).to(DEV)
+    assert torch.equal(host_perm, hb.word_perm(ids)), "host (numpy stable argsort) and device (torch stable sort) permutations differ"
+    run = lambda perm: hb.embed_ln_bwd(ids, seg, pos, word, tt, pt, gam, stats, dout, B, S, word_pad_id=1, pos_pad_id=pos_pad, perm=perm)
+    a, b_ = run(host_perm), run(None)
+    names = ("dword", "dtype", "dpos", "dgamma", "dbeta")
+    for n, x, y, want in zip(names, a, b_, (wr.grad, tr.grad, pr.grad, gr.grad, br.grad)):
+        assert torch.equal(x, y), "embed_bwd %s is not bit-reproducible" % n
+        close("embed_bwd(seg) %s" % n, x, want, tol)
+    assert a[0][1].abs().max().item() == 0.0                 # padding row
+    # accumulation (the ASR pass on top of the transcript pass): twice the gradient, and still the same bits on a second run
+    acc1 = hb.embed_ln_bwd(ids, seg, pos, word, tt, pt, gam, stats, dout, B, S, word_pad_id=1, pos_pad_id=pos_pad, perm=host_perm,
+                           accumulate_into=tuple(t.clone() for t in a))
+    acc2 = hb.embed_ln_bwd(ids, seg, pos, word, tt, pt, gam, stats, dout, B, S, word_pad_id=1, pos_pad_id=pos_pad, perm=host_perm,
+                           accumulate_into=tuple(t.clone() for t in a))
+    for n, x, y, one in zip(names, acc1, acc2, a):
+        assert torch.equal(x, y), "accumulating embed_bwd %s is not bit-reproducible" % n
+        assert torch.equal(x, one + one), "accumulate: %s != 2 x the single pass" % n
+    # dropout on: the mask is regenerated from the counter, identically in the two token kernels
+    d1 = hb.embed_ln_bwd(ids, seg, pos, word, tt, pt, gam, stats, dout, B, S, word_pad_id=1, pos_pad_id=pos_pad, perm=host_perm, drop_p=0.1, seed=3, drop_stream=5)
+    d2 = hb.embed_ln_bwd(ids, seg, pos, word, tt, pt, gam, stats, dout, B, S, word_pad_id=1, pos_pad_id=pos_pad, perm=host_perm, drop_p=0.1, seed=3, drop_stream=5)
+    for n, x, y in zip(names, d1, d2):
+        assert torch.equal(x, y), n
+
+
 # ------------------------------------------------------------------------------------------------
 def _attn_ref(qkv, mask, B, S, heads):
     H = heads * 64

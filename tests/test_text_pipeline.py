@@ -157,11 +157,11 @@ def test_f1_trajectory_tracks_reference_loop(dtype, labels):
       * after that, 144 Adam steps amplify a 1e-6 difference into a different trajectory: the fp32 HIP path ends 1-2 F1 points away
         from the reference run of the same seed, like any other draw.  So the comparable quantity is the MEAN over the seeds (the
         reference's README reports its F1 the same way), compared PAIRED per seed: the mean difference of the final held-out F1 (and of the
-        final train F1) of every dtype must lie within 3 standard errors of the per-seed differences, at least 1.5 and at most 4 pt
-        (one held-out label decision = 0.35 pt; the per-seed differences scatter by 2 - 2.5 pt, so an 8-seed mean resolves ~0.8 pt:
-        0.2 pt is below what 128 held-out utterances and 8 seeds can resolve).  The step is not bit-reproducible run to run (float atomics
-        of the word-table scatter), so the bf16 / fp8w means themselves move by ~1 pt between two runs of this test: a fixed 1.5-pt bar on
-        the train mean failed once in four runs at 1.55."""
+        final train F1) of every dtype must lie within 1.5 pt (one held-out label decision = 0.35 pt; the per-seed differences scatter by
+        2 - 2.5 pt, so an 8-seed mean resolves ~0.8 pt: 0.2 pt is below what 128 held-out utterances and 8 seeds can resolve).
+        Round 3 had to widen this to min(max(1.5, 3 SE), 4): the step was not bit-reproducible (float atomics of the word-table
+        scatter) and the bf16 / fp8w means moved by ~1 pt between two runs of this very test.  Round 4: the step is deterministic, the
+        trajectories are the same on every run, and the bound is the fixed 1.5 pt again."""
     from nbest_amd.model import NBestSTCModel
     from nbest_amd.optim import HipBertAdam
     z = np.load(os.path.join(GOLDEN, "case_traj.npz"))
@@ -200,12 +200,11 @@ def test_f1_trajectory_tracks_reference_loop(dtype, labels):
     ref_he, ref_tr = z["held"][:, -1, 3], z["train"][:, -1, 3]
     print("traj %-4s MEAN over %d seeds: final held-out F1 %.2f (reference %.2f, seed std %.2f) | final train F1 %.2f (reference %.2f)" % (
         dtype, len(fin_he), np.mean(fin_he), ref_he.mean(), ref_he.std(ddof=1), np.mean(fin_tr), ref_tr.mean()))
-    # paired over the seeds (same initialisation, same batches): the mean difference must not be significant - within 3 standard errors
-    # of the per-seed differences (never tighter than 1.5 pt: eight draws also mis-estimate their own spread) - nor gross (4 pt)
+    # paired over the seeds (same initialisation, same batches): the mean difference within a FIXED 1.5 pt
     for what, got, ref in (("held-out", np.asarray(fin_he), ref_he), ("train", np.asarray(fin_tr), ref_tr)):
         d = got - ref
         se = d.std(ddof=1) / np.sqrt(len(d))
-        bound = min(max(1.5, 3.0 * se), 4.0)
+        bound = 1.5
         print("traj %-4s %-8s F1: mean difference %+.2f pt, standard error %.2f, bound %.2f" % (dtype, what, d.mean(), se, bound))
         assert abs(d.mean()) <= bound, (dtype, what, d.mean(), se, bound)
 
