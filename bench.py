@@ -176,6 +176,47 @@ def note(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+def real_data_throughput(model, optim, labels, batch_size, n_best, epochs=2, min_utts=16384):
+    """VERDICT r3 item 8 / SURVEY 8f-1: the REAL-data loop - the shipped `valid` split (tests/golden/valid_512.txt: 512 lines of
+    the reference's dstc2 valid file) tiled to >= 16 k utterances, through trainer.EncodedSplit (tokenised once) + Prefetcher
+    (pinned host batches, side-stream H2D) + trainer.train_epoch (the step, the device decode and the host F1 bookkeeping of
+    /root/reference/n_best_asr_bert.py:232-294).  Batches pad to their own longest row, so the comparable quantity is PADDED
+    TOKENS per second.  Returns a dict for the JSON line; epoch 0 warms the shape cache, the last epoch is the one reported."""
+    import types
+    from nbest_amd import inputs, trainer
+    vocab = json.load(open(os.path.join(ROOT, "tests", "golden", "text_vocab.json")))
+    z = np.load(os.path.join(ROOT, "tests", "golden", "case_text.npz"))
+    memory = dict(label2idx=json.loads(str(z["label2idx"])), idx2label=labels.idx2label)
+    data = trainer.read_wcn_data(os.path.join(ROOT, "tests", "golden", "valid_512.txt"))
+    reps = (min_utts + len(data[0]) - 1) // len(data[0])
+    data = tuple(list(x) * reps for x in data)
+    opt = types.SimpleNamespace(batchSize=batch_size, tokenizer=inputs.WordPieceTokenizer(vocab), pre_trained_model="bert",
+                                tod_pre_trained_model=None, without_system_act=False, add_l2_loss=False, add_segment_ids=True,
+                                n_best=n_best, max_seq_len=None, random_seed=999, optimizer=optim)
+    t0 = time.time()
+    split = trainer.EncodedSplit(data, opt, memory)
+    t_tok = time.time() - t0
+    lens = np.array([len(r[0]) for r in split.rows])
+    res = {}
+    for ep in range(epochs):
+        lists = trainer.batch_indices(len(split), batch_size, shuffle=True, seed=999 + ep)
+        padded = int(sum(len(ix) * lens[ix].max() for ix in lists))
+        torch.cuda.synchronize()
+        t0 = time.time()
+        loss, (p, r, f), acc = trainer.train_epoch(model, split, opt, memory, epoch=ep)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        res = dict(utterances=len(split), epochs=epochs, reported_epoch=ep, batch=batch_size, n_best=n_best, steps=len(lists),
+                   seconds=round(dt, 3), utterances_per_s=round(len(split) / dt, 1), padded_tokens=padded,
+                   padded_tokens_per_s=round(padded / dt, 0), mean_padded_len=round(padded / len(split), 1),
+                   max_len=int(lens.max()), tokenise_once_s=round(t_tok, 2), loss=round(float(loss), 3), f1=round(float(f), 2),
+                   includes="EncodedSplit batches from pinned memory (Prefetcher, side-stream H2D), train_step, device decode + host F1 "
+                            "bookkeeping one step behind (MetricsPipe), no host synchronisation inside the epoch")
+        note("real data epoch %d: %.2f s, %.0f utt/s, %.0f padded tokens/s (mean padded length %.1f)" % (
+            ep, dt, len(split) / dt, padded / dt, padded / len(split)))
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +235,9 @@ def main():
     ap.add_argument("--shard_optimizer", default="off", choices=["auto", "on", "off"],
                     help="data parallel: BertAdam sharded over the ranks (auto: models over 200 M parameters - see DESIGN 6)")
     ap.add_argument("--no_packed_weights", action="store_true", help="A/B diagnostic: the GEMMs read the weight matrices row by row (round-2 behaviour)")
+    ap.add_argument("--real", action="store_true", help="after the synthetic measurement: the real-data loop (shipped valid split tiled to 16 k utterances "
+                    "through EncodedSplit + Prefetcher + train_epoch, decode and F1 included) as a second JSON key `real_data` (N = 1 only)")
+    ap.add_argument("--epochs", type=int, default=2, help="--real: epochs over the tiled split (the last one is reported)")
     a = ap.parse_args()
 
     # NBEST_BENCH_REHEARSAL=1: the N ranks share cuda:0 and talk through gloo - the whole multi-rank code path (sharded optimizer,
@@ -332,6 +376,12 @@ def main():
                                "timing": "HIP events recorded by the library around each of the %d launches per step, on the launch "
                                          "stream, inside 3 training steps run right after the timed region" % (wpl * cfg.num_hidden_layers),
                                "avg_launch_ms": round(ms, 4), "flops_per_launch": fl, "algorithmic_bytes_per_launch": by}
+        if a.real and world == 1:
+            rd = real_data_throughput(model, optim, labels, a.batch, a.n_best, epochs=a.epochs)
+            syn_tok = a.batch * a.seq_len * a.steps / dt
+            rd["synthetic_padded_tokens_per_s"] = round(syn_tok, 0)
+            rd["real_over_synthetic_at_equal_padded_tokens"] = round(rd["padded_tokens_per_s"] / syn_tok, 3)
+            res["real_data"] = rd
         if world == 1 and not a.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")
             res["cpu_baseline"] = cpu_baseline(labels)

@@ -174,10 +174,13 @@ typedef struct nbest_gemm_fp8_args {
   uint64_t seed;
   const float* out_scale_dev; /* optional DEVICE scalar that overrides out_scale (scales produced on the device by
                                  nbest_quantize_weights_fp8: no host round trip) */
-  /* ---- dgrad use (epilogues NONE, RES, DGELU): A8 is the e4m3 copy of a GRADIENT tensor, e4m3(g * s) with
-   * s = 2^floor(log2(56 / amax)) of the amax stored (as float bits) at a_amax; the accumulator is divided by s.
+  /* ---- scaled A operand (every epilogue): A8 = e4m3(a * s) with s = 2^floor(log2(T / amax)) of the amax stored (as float
+   * bits) at a_amax - the DELAYED per-tensor scale its producer used: a gradient tensor (dgrad epilogues NONE, RES, DGELU:
+   * T = 56, 8 x headroom) or, round 4, a forward activation (BIAS, BIAS_GELU, BIAS_DROP_RES: T = 224, 2 x headroom); the
+   * accumulator is divided by s.  NULL = unit scale.
    * DGELU: C = acc * gelu'(U) in bf16; optional C8 = e4m3(C * s_c), s_c from *c8_amax_prev; *c8_amax_new = max(|C|) (atomic);
-   * optional colsum_out[N] (+)= column sums of C (the FFN-up bias gradient), needs ws >= nbest_gemm_fp8_ws_bytes().   */
+   * optional colsum_out[N] (+)= column sums of C (the FFN-up bias gradient), needs ws >= nbest_gemm_fp8_ws_bytes().
+   * BIAS_GELU: C8 = e4m3(gelu * s_c) with the same two fields (the activation scale of the FFN-down GEMM's input).          */
   const uint32_t* a_amax;
   const uint32_t* c8_amax_prev;
   uint32_t* c8_amax_new;
@@ -195,20 +198,22 @@ size_t nbest_gemm_fp8_ws_bytes(const nbest_gemm_fp8_args* a);
 int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t stream);
 /* fp8 weight gradient: dW[M][N] (fp32) (+)= sum over K tokens of dY8[k][m] * X8[k][n] / s, both operands TOKEN-major e4m3
  * ([K][lda] / [K][ldb], as their producers wrote them: the reduction dimension is read through transposed LDS reads),
- * s = the gradient scale of dY8 (from the float bits at a_amax, NULL = 1).  M, N multiples of 256; split-K over tokens into
- * ws (>= nbest_wgrad_fp8_ws_bytes) + deterministic reduce.  Replaces the weight-gradient half of the nn.Linear backward. */
+ * s = the gradient scale of dY8 (from the float bits at a_amax, NULL = 1) times the activation scale of X8 (x_amax, NULL = 1).
+ * M, N multiples of 256; split-K over tokens into ws (>= nbest_wgrad_fp8_ws_bytes) + deterministic reduce.  Replaces the
+ * weight-gradient half of the nn.Linear backward. */
 size_t nbest_wgrad_fp8_ws_bytes(int64_t M, int64_t N, int64_t K);
 int nbest_wgrad_fp8(const void* dY8, const void* X8, float* dW, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                    int64_t ldc, const uint32_t* a_amax, int accumulate, void* ws, size_t ws_bytes, nbest_stream_t stream);
+                    int64_t ldc, const uint32_t* a_amax, const uint32_t* x_amax, int accumulate, void* ws, size_t ws_bytes,
+                    nbest_stream_t stream);
 /* Two fp8 weight gradients with the same token dimension K and column count N in ONE launch (the e4m3 counterpart of nbest_wgrad_pair;
  * nbest_encoder_backward pairs the Q|K|V and attention-output gradients of a layer): problem b's 256 x 256 output tiles are appended below
  * problem a's, each keeps its own gradient scale (amax_a / amax_b), one reduce writes dWa and dWb.  Ma, Mb, N multiples of 256; ws >=
  * nbest_wgrad_fp8_pair_ws_bytes (0 = the pair does not fit: issue two nbest_wgrad_fp8).                                                */
 size_t nbest_wgrad_fp8_pair_ws_bytes(int64_t Ma, int64_t Mb, int64_t N, int64_t K);
 int nbest_wgrad_fp8_pair(const void* dY8a, const void* X8a, float* dWa, int64_t Ma, int64_t lda_a, int64_t ldb_a, int64_t ldc_a,
-                         const uint32_t* amax_a, const void* dY8b, const void* X8b, float* dWb, int64_t Mb, int64_t lda_b, int64_t ldb_b,
-                         int64_t ldc_b, const uint32_t* amax_b, int64_t N, int64_t K, int accumulate, void* ws, size_t ws_bytes,
-                         nbest_stream_t stream);
+                         const uint32_t* amax_a, const uint32_t* xamax_a, const void* dY8b, const void* X8b, float* dWb, int64_t Mb,
+                         int64_t lda_b, int64_t ldb_b, int64_t ldc_b, const uint32_t* amax_b, const uint32_t* xamax_b, int64_t N, int64_t K,
+                         int accumulate, void* ws, size_t ws_bytes, nbest_stream_t stream);
 /* bf16 [n] -> e4m3 [n], unit scale, saturating at +-448 (activations that feed an fp8 GEMM); n % 8 == 0 */
 int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream);
 
@@ -293,6 +298,14 @@ int nbest_stc_heads(const void* hidden, int64_t cls_stride, const float* Wh, con
                     float* loss_parts, float* dcls, float* dWh, float* dbh, int B, int H, int dtype,
                     int need_grad, int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
                     size_t ws_bytes, nbest_stream_t stream);
+/* Backward of the heads for ARBITRARY upstream gradients dtop [B][n_top], dbott [B][R - n_top], dfin [B][n_bottom] (fp32) - what
+ * torch autograd hands to the heads when the reference's loop calls total_loss.backward() on a loss it built itself
+ * (/root/reference/n_best_asr_bert.py:255-264; nbest_amd.model's autograd bridge).  `ws` must be the workspace of the
+ * nbest_stc_heads call (need_grad = 0 is enough) that produced top / bott for the same inputs and dropout seed: it holds the fp32
+ * CLS rows and the dropout bits.  dcls [B][H] overwritten; dWh / dbh overwritten unless accumulate.                                */
+int nbest_stc_heads_vjp(const float* Wh, const nbest_label_space* ls, const float* top, const float* bott, const float* dtop,
+                        const float* dbott, const float* dfin, float* dcls, float* dWh, float* dbh, int B, int H, int accumulate,
+                        float drop_p, uint64_t seed, uint32_t drop_stream, void* ws, size_t ws_bytes, nbest_stream_t stream);
 
 /* K8  pooled-CLS MSE auxiliary loss (--add_l2_loss): nn.MSELoss() between the ASR and transcript CLS
  * rows, /root/reference/n_best_asr_bert.py:166-170,574.  loss[0] = mean((a-t)^2);
@@ -407,8 +420,8 @@ typedef struct nbest_encoder_desc {
   void** wgrad_events;
   /* optional fp8 forward ("fp8w"; dtype must be NBEST_BF16): e4m3 copy of the weight arena (one byte per element at the
    * same element offsets) and its per-matrix inverse scales [4 L] (QKV, attention-out, FFN-up, FFN-down per layer), both
-   * from nbest_quantize_weights_fp8.  The forward GEMMs then run on the block-scaled fp8 MFMA (activations are cast to
-   * e4m3 with unit scale on the way in); everything else, and the whole backward, is the bf16 path.                      */
+   * from nbest_quantize_weights_fp8.  The forward GEMMs then run on the block-scaled fp8 MFMA; their activation operands
+   * are e4m3 copies written by the producers with a DELAYED per-tensor scale (aamax_* below); everything else is the bf16 path. */
   const void* w8;
   const float* w8_inv_scale;
   /* optional fp8 dgrads (needs w8): transposed e4m3 weight copy and the per-(layer, tensor) gradient amax history, uint32
@@ -431,6 +444,16 @@ typedef struct nbest_encoder_desc {
   /* REQUIRED by nbest_encoder_backward(with_embeddings): token indices of THIS pass sorted by word id (stable), int32 [B*S], device
    * memory - see nbest_embed_ln_bwd.  Set per call like `seed` (it belongs to the batch, not to the shape).                        */
   const int32_t* word_perm;
+  /* fp8 forward: activation amax history, uint32 float bits [4 L]: index 4 l + {0: layer input x (QKV GEMM), 1: ctx (attention-out
+   * GEMM), 2: x1 (FFN-up GEMM), 3: gelu(u) (FFN-down GEMM)}.  Every forward pass RECORDS this pass's amax into aamax_new (when
+   * non-NULL).  With fp8_act != 0 (a history exists in aamax_prev) the producers write e4m3(a * s), s = 2^floor(log2(224 / amax_prev)),
+   * the GEMMs divide by s (and the fp8 weight gradients of the backward, which read the same copies, too); with fp8_act == 0 the
+   * forward is a CALIBRATION pass: it runs the bf16 GEMMs and only records the amax.  The caller swaps prev / new after every
+   * step (after the backward, which reads the copies scaled by prev) and sets fp8_act once a history exists.                     */
+  const uint32_t* aamax_prev;
+  uint32_t* aamax_new;
+  int32_t fp8_act;
+  int32_t pad4;
 } nbest_encoder_desc;
 size_t nbest_encoder_act_bytes(const nbest_encoder_desc* d);
 size_t nbest_encoder_ws_bytes(const nbest_encoder_desc* d);

@@ -226,7 +226,12 @@ template <int NKB, bool DROP>
 __global__ __launch_bounds__(256, (NKB <= 4 ? (DROP ? 3 : 4) : 1)) void attn_fwd_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                             bf16* __restrict__ ctx, float* __restrict__ lse, int S, int heads,
                                                             int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8,
-                                                            uint32_t* __restrict__ keep_out) {
+                                                            uint32_t* __restrict__ keep_out, const uint32_t* __restrict__ a_prev,
+                                                            uint32_t* __restrict__ a_new) {
+  // ctx8 (fp8 forward): e4m3(ctx * s), s = 2^floor(log2(224 / amax)) from the amax ctx had in the previous pass (a_prev, delayed
+  // scaling: common.h fp8_ascale_of); this pass's amax goes to a_new.  Both null: unit scale, nothing recorded.
+  const float s8 = fp8_act_scale(a_prev);
+  float amax8 = 0.f;
   // keep_out (optional, with dropout): the keep decisions as bit words [bh][key block][query] (bit j = key 32 kb + j kept), so
   // that the backward pass reads one word per (query, key block) instead of hashing every score element again
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -365,7 +370,11 @@ __global__ __launch_bounds__(256, (NKB <= 4 ? (DROP ? 3 : 4) : 1)) void attn_fwd
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[kb][s], tr_frag<true>(Vt, 32 * kb + 16 * s, 32, lane), o1, 0, 0, 0);
       }
     store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0,
-               ctx8 ? ctx8 + ((int64_t)b * S + q0) * H + h * 64 : nullptr);
+               ctx8 ? ctx8 + ((int64_t)b * S + q0) * H + h * 64 : nullptr, s8, amax8, a_new != nullptr);
+  }
+  if (a_new) {
+    amax8 = wave_max(amax8);
+    if (lane == 0) amax_update(a_new, amax8);
   }
 }
 
@@ -744,7 +753,10 @@ __device__ __forceinline__ void stage_rows_off(__amdgpu_buffer_rsrc_t rs, char* 
 
 __global__ __launch_bounds__(256) void attn_fwd_long_bf16_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                                  bf16* __restrict__ ctx, float* __restrict__ lse, int S, int nkb,
-                                                                 int heads, int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8) {
+                                                                 int heads, int H, float scale, DropCfg drop, uint8_t* __restrict__ ctx8,
+                                                                 const uint32_t* __restrict__ a_prev, uint32_t* __restrict__ a_new) {
+  const float s8 = fp8_act_scale(a_prev);       // see attn_fwd_bf16_kernel
+  float amax8 = 0.f;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int Sp = nkb * 32;
   char* Kt = lds;
@@ -844,7 +856,11 @@ __global__ __launch_bounds__(256) void attn_fwd_long_bf16_kernel(const bf16* __r
       }
     }
     store_tile(Ost + wave * 4096, 0, o0, o1, lane, ctx + ((int64_t)b * S + q0) * H + h * 64, H, S - q0,
-               ctx8 ? ctx8 + ((int64_t)b * S + q0) * H + h * 64 : nullptr);
+               ctx8 ? ctx8 + ((int64_t)b * S + q0) * H + h * 64 : nullptr, s8, amax8, a_new != nullptr);
+  }
+  if (a_new) {
+    amax8 = wave_max(amax8);
+    if (lane == 0) amax_update(a_new, amax8);
   }
 }
 
@@ -1066,14 +1082,14 @@ static size_t bwd_lds_bytes(int nkb) { return (size_t)nkb * 32 * (4 * 128 + 256)
 
 template <int NKB>
 static void launch_fwd(const bf16* qkv, const uint8_t* mask, bf16* ctx, float* lse, int B, int S, int heads, int H, float scale,
-                       DropCfg d, hipStream_t st, uint8_t* ctx8, uint32_t* keep) {
+                       DropCfg d, hipStream_t st, uint8_t* ctx8, uint32_t* keep, const uint32_t* a_prev, uint32_t* a_new) {
   const size_t sm = fwd_lds_bytes(NKB);
   if (d.thr16) {     // the dropout-free instantiation (evaluation, parity runs) carries no hash and no keep words: 58 -> 47 us at S = 128
     (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    attn_fwd_bf16_kernel<NKB, true><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8, keep);
+    attn_fwd_bf16_kernel<NKB, true><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8, keep, a_prev, a_new);
   } else {
     (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<NKB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-    attn_fwd_bf16_kernel<NKB, false><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8, keep);
+    attn_fwd_bf16_kernel<NKB, false><<<B * heads, 256, sm, st>>>(qkv, mask, ctx, lse, S, heads, H, scale, d, ctx8, keep, a_prev, a_new);
   }
 }
 #ifdef NBEST_EXPERIMENTS
@@ -1105,7 +1121,7 @@ size_t nbest_internal_attention_keep_bytes(int B, int S, int heads) {
 }
 int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void* ctx, void* ctx8, float* lse, int B, int S, int heads,
                                   int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream,
-                                  uint32_t* keep) {
+                                  uint32_t* keep, const uint32_t* a_prev, uint32_t* a_new) {
   NB_CHECK(qkv && key_mask && ctx && lse, NBEST_ERR_ARG, "attention_fwd: null pointer");
   if (int e = check_common("attention_fwd", B, S, heads, d, dtype)) return e;
   hipStream_t st = (hipStream_t)stream;
@@ -1122,11 +1138,11 @@ int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void
     if (nkb > 8) {
       const size_t sm = fwd_lds_bytes(nkb);
       (void)hipFuncSetAttribute((const void*)attn_fwd_long_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-      attn_fwd_long_bf16_kernel<<<B * heads, 256, sm, st>>>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, S, nkb, heads, H, scale, dc, (uint8_t*)ctx8);
+      attn_fwd_long_bf16_kernel<<<B * heads, 256, sm, st>>>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, S, nkb, heads, H, scale, dc, (uint8_t*)ctx8, a_prev, a_new);
       NB_LAUNCH_CHECK();
       return NBEST_OK;
     }
-#define F(N) case N: launch_fwd<N>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, S, heads, H, scale, dc, st, (uint8_t*)ctx8, keep); break;
+#define F(N) case N: launch_fwd<N>((const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, S, heads, H, scale, dc, st, (uint8_t*)ctx8, keep, a_prev, a_new); break;
     switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
 #undef F
   }
@@ -1136,7 +1152,7 @@ int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void
 
 extern "C" int nbest_attention_fwd(const void* qkv, const uint8_t* key_mask, void* ctx, float* lse, int B, int S, int heads,
                                    int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream) {
-  return nbest_internal_attention_fwd8(qkv, key_mask, ctx, nullptr, lse, B, S, heads, d, dtype, drop_p, seed, drop_stream, stream, nullptr);
+  return nbest_internal_attention_fwd8(qkv, key_mask, ctx, nullptr, lse, B, S, heads, d, dtype, drop_p, seed, drop_stream, stream, nullptr, nullptr, nullptr);
 }
 
 int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
@@ -1215,7 +1231,7 @@ extern "C" int nbest_attention_fwd_keep(const void* qkv, const uint8_t* key_mask
                                         nbest_stream_t stream) {
   const bool ok = keep && dtype == NBEST_BF16 && nbest_internal_attention_keep_bytes(B, S, heads) > 0;
   return nbest_internal_attention_fwd8(qkv, key_mask, ctx, nullptr, lse, B, S, heads, d, dtype, drop_p, seed, drop_stream, stream,
-                                       ok ? (uint32_t*)keep : nullptr);
+                                       ok ? (uint32_t*)keep : nullptr, nullptr, nullptr);
 }
 extern "C" int nbest_attention_bwd_keep(const void* qkv, const uint8_t* key_mask, const void* ctx, const void* dctx, const float* lse,
                                         void* dqkv, float* dbias, int accumulate, void* ws, size_t ws_bytes, int B, int S, int heads,

@@ -346,6 +346,13 @@ __host__ __device__ __forceinline__ float fp8_pow2_scale(float amax, float targe
 __host__ __device__ __forceinline__ float fp8_scale_of(float amax) { return fp8_pow2_scale(amax, 224.f); }        // weights
 __host__ __device__ __forceinline__ float fp8_gscale_of(float amax) { return fp8_pow2_scale(amax, 56.f); }        // gradients
 __device__ __forceinline__ float fp8_grad_scale(const uint32_t* amax_prev) { return amax_prev ? fp8_gscale_of(__uint_as_float(*amax_prev)) : 1.f; }
+// Forward ACTIVATIONS of the fp8 mode (x, ctx, x1, gelu(u)): the same delayed per-tensor scale, but with 2 x headroom (the amax maps to
+// 112 .. 224, as the weights).  Activations move slowly from one step to the next, and what a scale costs is at the BOTTOM: every
+// halving of the scale pushes another octave of the small entries into e4m3's subnormals.  Measured on the outlier-statistics golden
+// (amax 260 under a bulk of O(1)): with the gradients' 8 x headroom the scaled copy was WORSE than the unit-scale one it replaces
+// (score floor 8.7e-2 against 6.1e-2) - the bulk paid for headroom the outliers did not need.
+__host__ __device__ __forceinline__ float fp8_ascale_of(float amax) { return fp8_pow2_scale(amax, 224.f); }
+__device__ __forceinline__ float fp8_act_scale(const uint32_t* amax_prev) { return amax_prev ? fp8_ascale_of(__uint_as_float(*amax_prev)) : 1.f; }
 // *p = max(*p, v) for one lane of a wave.  Thousands of waves update the same word: an unconditional atomicMax from each
 // serialises at the L2 (measured: +66 us on a 126 us kernel for 12 288 atomics); reading first lets all but the few waves
 // that actually raise the maximum skip the atomic.

@@ -13,7 +13,8 @@
 #include "common.h"
 
 int nbest_internal_layernorm_fwd8(const void* x, const float* gamma, const float* beta, void* y, void* y8, float* stats,
-                                  int64_t M, int H, float eps, int dtype, nbest_stream_t stream);
+                                  int64_t M, int H, float eps, int dtype, nbest_stream_t stream, const uint32_t* a_prev, uint32_t* a_new);
+int nbest_internal_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, const uint32_t* a_prev, uint32_t* a_new, hipStream_t st);
 int nbest_internal_layernorm_bwd8(const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
                                   void* dx_drop, float* dgamma, float* dbeta, float* dbias, int64_t M, int H, int dtype,
                                   int accumulate, float drop_p, uint64_t seed, uint32_t drop_stream, void* ws,
@@ -28,7 +29,8 @@ void nbest_internal_rowred_batch_begin();
 void nbest_internal_rowred_batch_abort();
 int nbest_internal_rowred_batch_flush(hipStream_t st);
 int nbest_internal_attention_fwd8(const void* qkv, const uint8_t* key_mask, void* ctx, void* ctx8, float* lse, int B, int S, int heads,
-                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, uint32_t* keep);
+                                  int d, int dtype, float drop_p, uint64_t seed, uint32_t drop_stream, nbest_stream_t stream, uint32_t* keep,
+                                  const uint32_t* a_prev, uint32_t* a_new);
 
 namespace {
 
@@ -155,8 +157,13 @@ static WsLayout ws_layout(const nbest_encoder_desc* d) {
 
 // the backward of this pass runs its dgrad / wgrad GEMMs in fp8 (same answer in the forward, which then leaves out the
 // bf16 tensors only a bf16 backward would read, and in the backward)
+// the forward of this pass runs its GEMMs in fp8: needs the activation amax history (fp8_act; without one the pass is a calibration
+// pass on the bf16 GEMMs that records it)
+static bool fp8_forward_active(const nbest_encoder_desc* d) {
+  return d->dtype == NBEST_BF16 && d->w8 && d->w8_inv_scale && d->fp8_act && d->aamax_prev;
+}
 static bool fp8_backward_active(const nbest_encoder_desc* d) {
-  return d->dtype == NBEST_BF16 && d->w8 && d->fp8_bwd && d->w8t && d->w8_inv_scale && d->gamax_prev && d->gamax_new;
+  return fp8_forward_active(d) && d->fp8_bwd && d->w8t && d->gamax_prev && d->gamax_new;   // reads the forward's e4m3 activation copies
 }
 
 static int check_desc(const nbest_encoder_desc* d) {
@@ -220,7 +227,10 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
   const ActLayout a = act_layout(d);
   NB_CHECK(act_bytes >= a.total, NBEST_ERR_WORKSPACE, "encoder_forward: activation stash too small (%zu < %zu)", act_bytes, a.total);
   hipStream_t st = (hipStream_t)stream;
-  const bool f8 = d->w8 && d->w8_inv_scale && d->dtype == NBEST_BF16;
+  const bool f8 = fp8_forward_active(d);
+  const bool arec = d->w8 && d->aamax_new && d->dtype == NBEST_BF16;     // record the activation amax of this pass (fp8 or calibration)
+  auto AP = [&](int idx) -> const uint32_t* { return f8 ? d->aamax_prev + idx : nullptr; };
+  auto AN = [&](int idx) -> uint32_t* { return arec ? d->aamax_new + idx : nullptr; };
   const WsLayout wl = ws_layout(d);
   if (f8) NB_CHECK(ws && ws_bytes >= wl.total, NBEST_ERR_WORKSPACE, "encoder_forward(fp8): workspace too small (%zu < %zu)", ws_bytes, wl.total);
   const Ptrs P{(const char*)wts, prm, a.esz};
@@ -244,8 +254,12 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N; g.ldu = N; g.ldc8 = N;
     if (d->w8p) { g.B_packed = (const uint8_t*)d->w8p + w_off; g.b_pack_bn = nbest_pack_bn_fp8(N, K); }
     g.epilogue = epi; g.out_scale = 1.f; g.out_scale_dev = d->w8_inv_scale + mat; g.drop_p = drop_p; g.drop_stream = stream_id; g.seed = d->seed;
+    g.a_amax = d->aamax_prev + mat;         // the A operand's delayed scale (activation index = matrix index: 4 l + {x, ctx, x1, gelu})
+    if (epi == NBEST_EPI_BIAS_GELU) { g.c8_amax_prev = d->aamax_prev + mat + 1; g.c8_amax_new = d->aamax_new ? d->aamax_new + mat + 1 : nullptr; }
     return nbest_gemm_fp8(&g, stream);
   };
+  // calibration pass (fp8 mode without an activation history): bf16 GEMMs, the amax of the four GEMM inputs of every layer recorded
+  auto calib = [&](const void* t, int64_t n, int idx) -> int { return (arec && !f8) ? nbest_internal_amax_bf16(t, n, d->aamax_new + idx, st) : NBEST_OK; };
   for (int l = 0; l < d->L; ++l) {
     const nbest_layer_offsets& o = d->layers_host[l];
     char* Lb = A + a.layer0 + (size_t)l * a.layer_stride;
@@ -257,20 +271,24 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     uint8_t* x8_next = (l + 1 < d->L) ? L8(l + 1, a.o_x8) : nullptr;   // the last LayerNorm's copy has no reader
     // QKV projection: [M,H] x [3H,H]^T + b
     if (f8) {
-      if (l == 0) RUN(nbest_cast_bf16_to_fp8(X(0), x8, M * H, stream));   // later layers: written by the previous layer's LayerNorm
+      if (l == 0) RUN(nbest_internal_cast_bf16_to_fp8(X(0), x8, M * H, AP(0), AN(0), st));   // later layers: written by the previous layer's LayerNorm
       RUN(gemm8(x8, o.wqkv, 4 * l + 0, qkv, 3 * H, H, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, nullptr, nullptr, 0.f, 0));
     } else
     RUN(gemm(dt, X(l), P.W(o.wqkv), qkv, M, 3 * H, H, H, H, 3 * H, 0, 0, NBEST_EPI_BIAS, P.P(o.bqkv), nullptr, 0, nullptr, 0,
              nullptr, 0, 0, 0.f, 0, 0, st, nullptr, PK(o.wqkv)));
     uint32_t* keepw = (a.keep_bytes && d->attn_drop > 0.f) ? (uint32_t*)(Lb + a.o_keep) : nullptr;
-    RUN(nbest_internal_attention_fwd8(qkv, key_mask, ctx, ctx8, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream, keepw));
+    RUN(calib(X(l), M * H, 4 * l + 0));
+    RUN(nbest_internal_attention_fwd8(qkv, key_mask, ctx, ctx8, lse, d->B, d->S, d->heads, 64, dt, d->attn_drop, d->seed, s0 + 0, stream, keepw,
+                                      AP(4 * l + 1), f8 ? AN(4 * l + 1) : nullptr));
+    RUN(calib(ctx, M * H, 4 * l + 1));
     // attention output projection + dropout + residual, then LayerNorm
     if (f8) {
       RUN(gemm8(ctx8, o.wo, 4 * l + 1, r1, H, H, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), nullptr, nullptr, d->hidden_drop, s0 + 1));
     } else
     RUN(gemm(dt, ctx, P.W(o.wo), r1, M, H, H, H, H, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.bo), X(l), H, nullptr, 0, nullptr, 0, 0,
              d->hidden_drop, d->seed, s0 + 1, st, nullptr, PK(o.wo)));
-    RUN(nbest_internal_layernorm_fwd8(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, x18, st1, M, H, d->ln_eps, dt, stream));
+    RUN(nbest_internal_layernorm_fwd8(r1, P.P(o.ln1_g), P.P(o.ln1_b), x1, x18, st1, M, H, d->ln_eps, dt, stream, AP(4 * l + 2), f8 ? AN(4 * l + 2) : nullptr));
+    RUN(calib(x1, M * H, 4 * l + 2));
     // FFN up + bias + GELU (GELU' of the pre-activation kept for the backward)
     if (f8) {
       // (bf16 gelu(u) has one reader, the bf16 FFN-down weight gradient: not written when the backward runs in fp8)
@@ -284,7 +302,9 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     } else
     RUN(gemm(dt, hact, P.W(o.w2), r2, M, H, F, F, F, H, 0, 0, NBEST_EPI_BIAS_DROP_RES, P.P(o.b2), x1, H, nullptr, 0, nullptr, 0, 0,
              d->hidden_drop, d->seed, s0 + 2, st, nullptr, PK(o.w2)));
-    RUN(nbest_internal_layernorm_fwd8(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), x8_next, st2, M, H, d->ln_eps, dt, stream));
+    RUN(calib(hact, M * F, 4 * l + 3));
+    RUN(nbest_internal_layernorm_fwd8(r2, P.P(o.ln2_g), P.P(o.ln2_b), X(l + 1), x8_next, st2, M, H, d->ln_eps, dt, stream,
+                                      x8_next ? AP(4 * l + 4) : nullptr, (f8 && x8_next) ? AN(4 * l + 4) : nullptr));
   }
   if (hidden_out) *hidden_out = X(d->L);
   return NBEST_OK;
@@ -380,7 +400,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
       if (rec) RUN(nbest_internal_amax_bf16(dBig, M * F, d->gamax_new + 4 * l + 1, st));   // calibration pass: this producer is a bf16 kernel
     }
     stamp(0);
-    if (f8b) RUN(nbest_wgrad_fp8(dRd8, h8, G(o.w2), H, F, M, H, F, F, d->gamax_prev + 4 * l + 0, accumulate, slab, w.slab_bytes, stream));
+    if (f8b) RUN(nbest_wgrad_fp8(dRd8, h8, G(o.w2), H, F, M, H, F, F, d->gamax_prev + 4 * l + 0, d->aamax_prev + 4 * l + 3, accumulate, slab, w.slab_bytes, stream));
     else RUN(gemm(dt, dRd, hact, G(o.w2), H, F, M, H, F, F, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
                   accumulate, 0.f, 0, 0, st));
     stamp(1);
@@ -388,7 +408,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     if (f8b) RUN(dgrad8(dBig8, 4 * l + 1, o.w1, 4 * l + 2, dB1, H, F, NBEST_EPI_RES, dR, nullptr, nullptr, -1, nullptr));
     else RUN(gemm(dt, dBig, PT.W(o.w1), dB1, M, H, F, F, wt ? F : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st, nullptr, PKT(o.w1)));
     stamp(0);
-    if (f8b) RUN(nbest_wgrad_fp8(dBig8, x18, G(o.w1), F, H, M, F, H, H, d->gamax_prev + 4 * l + 1, accumulate, slab, w.slab_bytes, stream));
+    if (f8b) RUN(nbest_wgrad_fp8(dBig8, x18, G(o.w1), F, H, M, F, H, H, d->gamax_prev + 4 * l + 1, d->aamax_prev + 4 * l + 2, accumulate, slab, w.slab_bytes, stream));
     else RUN(gemm(dt, dBig, x1, G(o.w1), F, H, M, F, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
                   accumulate, 0.f, 0, 0, st));
     stamp(1);
@@ -401,7 +421,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     // (bf16: this layer's dRd and ctx stay untouched until the next layer's LayerNorm backward - the gradient is issued below, with QKV's)
     if (!paired) {
       stamp(0);
-      if (f8b) RUN(nbest_wgrad_fp8(dRd8, ctx8, G(o.wo), H, H, M, H, H, H, d->gamax_prev + 4 * l + 2, accumulate, slab, w.slab_bytes, stream));
+      if (f8b) RUN(nbest_wgrad_fp8(dRd8, ctx8, G(o.wo), H, H, M, H, H, H, d->gamax_prev + 4 * l + 2, d->aamax_prev + 4 * l + 1, accumulate, slab, w.slab_bytes, stream));
       else RUN(gemm(dt, dRd, ctx, G(o.wo), H, H, M, H, H, H, 1, 1, NBEST_EPI_F32_SPLITK, nullptr, nullptr, 0, nullptr, 0, slab, w.slab_bytes,
                     accumulate, 0.f, 0, 0, st));
       stamp(1);
@@ -415,9 +435,10 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     else RUN(gemm(dt, dqkv, PT.W(o.wqkv), dA, M, H, 3 * H, 3 * H, wt ? 3 * H : H, H, 0, tbd, NBEST_EPI_RES, nullptr, dR, H, nullptr, 0, nullptr, 0, 0, 0.f, 0, 0, st, nullptr, PKT(o.wqkv)));
     stamp(0);
     if (f8b && paired)
-      RUN(nbest_wgrad_fp8_pair(dqkv8, x8, G(o.wqkv), 3 * H, 3 * H, H, H, d->gamax_prev + 4 * l + 3, dRd8, ctx8, G(o.wo), H, H, H, H,
-                               d->gamax_prev + 4 * l + 2, H, M, accumulate, slab, w.slab_bytes, stream));
-    else if (f8b) RUN(nbest_wgrad_fp8(dqkv8, x8, G(o.wqkv), 3 * H, H, M, 3 * H, H, H, d->gamax_prev + 4 * l + 3, accumulate, slab, w.slab_bytes, stream));
+      RUN(nbest_wgrad_fp8_pair(dqkv8, x8, G(o.wqkv), 3 * H, 3 * H, H, H, d->gamax_prev + 4 * l + 3, d->aamax_prev + 4 * l + 0, dRd8, ctx8, G(o.wo), H, H,
+                               H, H, d->gamax_prev + 4 * l + 2, d->aamax_prev + 4 * l + 1, H, M, accumulate, slab, w.slab_bytes, stream));
+    else if (f8b) RUN(nbest_wgrad_fp8(dqkv8, x8, G(o.wqkv), 3 * H, H, M, 3 * H, H, H, d->gamax_prev + 4 * l + 3, d->aamax_prev + 4 * l + 0, accumulate, slab,
+                                      w.slab_bytes, stream));
     else if (paired) {
       nbest_gemm_args g1 = {}, g2 = {};
       g1.A = dqkv; g1.B = X(l); g1.C = G(o.wqkv); g1.M = 3 * H; g1.lda = 3 * H;

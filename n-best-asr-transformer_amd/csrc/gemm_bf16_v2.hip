@@ -28,6 +28,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -207,6 +208,47 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* tile, int row_base, int
 template <int N> __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// helpers of the stripped ping-pong loop (gemm2_kernel, NT == 512 && kDirect): LDS-DMA of one K stage into ring buffer NB_ with
+// per-lane source offsets computed once (voA / voB) and the K advance in the scalar offset; fragment reads from ring buffer B_ (a
+// template constant: base register + immediate); the MFMA slot between its two workgroup barriers.
+template <int NB_, int STAGE, int A_BYTES, int NIA, int NIB, int NT, int BN>
+__device__ __forceinline__ void pp_issue(__amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, char* lds, const uint32_t* voA,
+                                         const uint32_t* voB, int wv, bool dumpB, char* dump, uint32_t sA, uint32_t sB) {
+#pragma unroll
+  for (int i = 0; i < NIA; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(lds + NB_ * STAGE + (i * NT + wv * 64) * 16), 16, voA[i], sA, 0, NB_AUX_A);
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    char* dst = lds + NB_ * STAGE + A_BYTES + (i * NT + wv * 64) * 16;
+    const bool d = ((BN * 4) % NT != 0) && i == NIB - 1 && dumpB;      // wave-uniform
+    if (d) dst = dump;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(dst), 16, voB[i], d ? 0u : sB, 0, NB_AUX_B);
+  }
+}
+template <int B_, int STAGE, int A_BYTES, int BM, int BN, int TMt, int TNt>
+__device__ __forceinline__ void pp_frags(const char* lds, bf16x8* af, bf16x8* bfr, int row0, int col0, int lane) {
+  const char* cur = lds + B_ * STAGE;
+#pragma unroll
+  for (int j = 0; j < TNt; ++j) bfr[j] = read_frag2<false, BN>(cur + A_BYTES, col0 + j * 16, lane);
+#pragma unroll
+  for (int i = 0; i < TMt; ++i) af[i] = read_frag2<false, BM>(cur, row0 + i * 16, lane);
+}
+template <int TMt, int TNt>
+__device__ __forceinline__ void pp_mfma_slot(const bf16x8* af, const bf16x8* bfr, f32x4 (&acc)[TMt][TNt]) {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int i = 0; i < TMt; ++i)
+#pragma unroll
+    for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 #define NB_STAMP(IDX)                                                                                          \
@@ -499,6 +541,112 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count
+  } else if constexpr (NT == 512 && kDirect && !(DIAG & 0x8000)) {
+    // ---- ping-pong as in the generic branch below (two wave groups one slot out of phase, LOAD slot | barrier | MFMA slot | barrier),
+    // with the LOAD slot stripped to its memory instructions (round 4).  The ISA of the generic branch spent, per slot: ~20 VALU
+    // instructions on addresses (per-lane DMA source offsets re-derived from k0, LDS destinations computed in VGPRs and moved to M0
+    // through v_readfirstlane, fragment addresses from the runtime ring index), and half a dozen scalar branches on conditions that
+    // are constant through the steady state (is a stage left to issue, how many may stay in flight, packed or plain B).  On a SIMD
+    // shared with a wave in its MFMA slot every VALU instruction of the loading wave takes a vector-issue slot from the MFMAs
+    // (MI355X_MICROARCH.md "Two waves per SIMD" item 2): the MFMA slot ran at 20 cycles per 16-cycle MFMA.  Here:
+    //   * the wave index is an SGPR (readfirstlane once): every LDS-DMA destination is scalar arithmetic -> s_mov m0;
+    //   * the per-lane DMA source offsets are computed ONCE (k0 = 0); the K advance travels in the instruction's scalar offset
+    //     (soffset; the range check that zero-fills rows >= M works on the per-lane offset, which holds the row);
+    //   * the ring index is a template constant inside a body unrolled over the ring: ds_read_b128 addresses are one per-lane base
+    //     plus an immediate;
+    //   * steady state (a stage to issue in every slot, two stages in flight behind the wait) and tail are separate code.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int grp = wv >> 2;
+    constexpr int NIA = (BM * 4) / NT, NIB = (BN * 4 + NT - 1) / NT;
+    static_assert((BM * 4) % NT == 0, "A tile: whole LDS-DMA instructions");
+    uint32_t voA[NIA], voB[NIB];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int pp = i * NT + tid, row = pp >> 2, slot = pp & 3, kc = slot ^ ((-(row >> 2)) & 3);
+      voA[i] = (uint32_t)(((m0a + row) * lda_ + kc * 8) * 2);
+    }
+    bool dumpB = false;     // this wave has no chunk in the last B instruction of a 192-row tile (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int pp = i * NT + tid;
+      if (b_packed) voB[i] = (uint32_t)pp * 16u;
+      else {
+        const int row = pp >> 2, slot = pp & 3, kc = slot ^ ((-(row >> 2)) & 3);
+        int grow = row;
+        if constexpr (kPW > 0) { const int x = row % kPW; grow = row - x + (kPW / 16) * (x & 15) + (x >> 4); }
+        voB[i] = (uint32_t)(((n0 + grow) * ldb_ + kc * 8) * 2);
+      }
+      if ((BN * 4) % NT != 0 && i == NIB - 1 && (i * NT + wv * 64) * 16 >= BN * 64) { voB[i] = 0xFFFFFFF0u; dumpB = true; }
+    }
+    const uint32_t sB0 = b_packed ? (uint32_t)(tile_n * nkt) * (uint32_t)B_BYTES : (uint32_t)(kbeg * 2);
+    const uint32_t sBstep = b_packed ? (uint32_t)B_BYTES : (uint32_t)(BK * 2);
+    char* const dump = lds + STAGES * STAGE + (wv % (NT / 64)) * 1024;
+    // (device function templates, not lambdas: the HOST pass of hipcc silently drops the kernel stub of every instantiation whose body
+    // calls a generic lambda that issues LDS-DMA builtins - the library then fails to load with an undefined kernel symbol)
+    bf16x8 af[TMt], bfr[TNt];
+    const uint32_t sA0 = (uint32_t)(kbeg * 2);
+#define PP_ISSUE(ST, NB_) pp_issue<(NB_), STAGE, A_BYTES, NIA, NIB, NT, BN>(rsA, rsB, lds, voA, voB, wv, dumpB, dump, sA0 + (uint32_t)(ST) * (uint32_t)(BK * 2), sB0 + (uint32_t)(ST) * sBstep)
+#define PP_FRAGS(B_) pp_frags<(B_), STAGE, A_BYTES, BM, BN, TMt, TNt>(lds, af, bfr, wm * WTM, wn * WTN, lane)
+#define PP_MFMA() pp_mfma_slot<TMt, TNt>(af, bfr, acc)
+    // steady-state slot kt (ring buffer B_ = kt % STAGES): issue stage kt + STAGES - 1, read the fragments of stage kt, retire this
+    // wave's share of stage kt + 1 (STAGES - 2 younger stages stay in flight), then the MFMA slot
+#define PP_STEADY(KT, B_)                                  \
+    do {                                                   \
+      PP_ISSUE((KT) + STAGES - 1, ((B_) + STAGES - 1) % STAGES); \
+      PP_FRAGS(B_);                                        \
+      wait_vm<(STAGES - 2) * NDMA>();                      \
+      PP_MFMA();                                           \
+    } while (0)
+    // tail / generic slot: runtime conditions as in the generic branch
+#define PP_GENERIC(KT, B_)                                                                          \
+    do {                                                                                            \
+      if ((KT) + STAGES - 1 < nk) PP_ISSUE((KT) + STAGES - 1, ((B_) + STAGES - 1) % STAGES);        \
+      PP_FRAGS(B_);                                                                                 \
+      const int c_ = (nk - 1 - (KT) < STAGES - 1) ? nk - 1 - (KT) : STAGES - 1;                     \
+      if (STAGES >= 5 && c_ >= 4) wait_vm<3 * NDMA>();                                              \
+      else if (c_ >= 3) wait_vm<2 * NDMA>();                                                        \
+      else if (c_ == 2) wait_vm<NDMA>();                                                            \
+      else if (c_ == 1) wait_vm<0>();                                                               \
+      PP_MFMA();                                                                                    \
+    } while (0)
+    // prologue: stages 0 .. STAGES-2 into buffers 0 .. STAGES-2
+    if (0 < nk) PP_ISSUE(0, 0);
+    if (1 < nk) PP_ISSUE(1, 1 % STAGES);
+    if (STAGES > 3 && 2 < nk) PP_ISSUE(2, 2 % STAGES);
+    if (STAGES > 4 && 3 < nk) PP_ISSUE(3, 3 % STAGES);
+    {
+      const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
+      if (STAGES >= 5 && younger >= 3) wait_vm<3 * NDMA>();
+      else if (younger >= 2) wait_vm<2 * NDMA>();
+      else if (younger == 1) wait_vm<NDMA>();
+      else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();                 // stage 0 landed for everyone
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
+    int kt = 0;
+    const int n_steady = nk - (STAGES - 1);        // slots that still have a stage to issue
+    for (; kt + STAGES <= n_steady; kt += STAGES) {
+      PP_STEADY(kt, 0);
+      PP_STEADY(kt + 1, 1);
+      PP_STEADY(kt + 2, 2);
+      if constexpr (STAGES > 3) PP_STEADY(kt + 3, 3 % STAGES);
+      if constexpr (STAGES > 4) PP_STEADY(kt + 4, 4 % STAGES);
+    }
+    // (kt is a multiple of STAGES here: slot kt + r uses ring buffer r)
+    for (; kt < nk; kt += STAGES) {
+      PP_GENERIC(kt, 0);
+      if (kt + 1 < nk) PP_GENERIC(kt + 1, 1);
+      if (kt + 2 < nk) PP_GENERIC(kt + 2, 2);
+      if constexpr (STAGES > 3) { if (kt + 3 < nk) PP_GENERIC(kt + 3, 3 % STAGES); }
+      if constexpr (STAGES > 4) { if (kt + 4 < nk) PP_GENERIC(kt + 4, 4 % STAGES); }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count
+#undef PP_ISSUE
+#undef PP_FRAGS
+#undef PP_MFMA
+#undef PP_STEADY
+#undef PP_GENERIC
   } else if constexpr (NT == 512) {
     // ---- ping-pong (8 waves = 2 groups of one wave per SIMD): a group alternates a LOAD slot (fragment
     // reads of stage j, LDS-DMA of stage j+STAGES-1, counted vmcnt) with an MFMA slot (stage j); group 1

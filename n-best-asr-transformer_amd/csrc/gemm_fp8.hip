@@ -124,8 +124,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
   f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
   if (kHasBias) { pb0 = *(const f32x4*)(p.bias + en8); pb1 = *(const f32x4*)(p.bias + en8 + 4); }
   float oscale = p.out_scale_dev ? *p.out_scale_dev : p.out_scale;
-  if (p.a_amax) oscale /= fp8_gscale_of(__uint_as_float(*p.a_amax));
-  const float c8s = fp8_grad_scale(p.c8g.amax_prev);
+  // A8 = e4m3(a * s): a gradient (dgrad epilogues, scale target 56) or a forward activation (forward epilogues, target 224)
+  constexpr bool kFwdEpi = (EPI == NBEST_EPI_BIAS || EPI == NBEST_EPI_BIAS_GELU || EPI == NBEST_EPI_BIAS_DROP_RES);
+  if (p.a_amax) oscale /= kFwdEpi ? fp8_ascale_of(__uint_as_float(*p.a_amax)) : fp8_gscale_of(__uint_as_float(*p.a_amax));
+  const float c8s = (EPI == NBEST_EPI_BIAS_GELU) ? fp8_act_scale(p.c8g.amax_prev) : fp8_grad_scale(p.c8g.amax_prev);
   float amax8 = 0.f;
   auto load_pre = [&](int64_t m) -> i32x4 {   // residual rows: bf16, 16 bytes per lane; GELU' rows: 8-bit, 8 bytes per lane
     if constexpr (kHasR) {
@@ -314,7 +316,11 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
         }
         if (!(DIAG8 & 512)) {
           st_stream((i32x2*)(p.U + oU), i32x2{(int)gd_pack4(gp), (int)gd_pack4(gp + 4)}, p.stream_out);
-          st_stream((i32x2*)(p.C8 + oC8), i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)}, p.stream_out);
+          // e4m3 copy of gelu(u) for the FFN-down GEMM, times the tensor's delayed scale (c8s = 1 without a history); this pass's amax
+          float q[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { q[e] = v[e] * c8s; amax8 = fmaxf(amax8, fabsf(v[e])); }
+          st_stream((i32x2*)(p.C8 + oC8), i32x2{(int)fp8_pack4(q), (int)fp8_pack4(q + 4)}, p.stream_out);
         } else if (gp[0] + gp[3] + gp[5] == 123.f) p.U[0] = 1;
       }
       if (EPI == NBEST_EPI_BIAS_DROP_RES && p.drop.thr16) {
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
       *(f32x4*)(o + 4) = f32x4{colacc[4], colacc[5], colacc[6], colacc[7]};
     }
   }
-  if (kHasUin && p.c8g.amax_new) {
+  if ((kHasUin || EPI == NBEST_EPI_BIAS_GELU) && p.c8g.amax_new) {
     amax8 = wave_max(amax8);
     if (lane == 0) amax_update(p.c8g.amax_new, amax8);
   }
@@ -379,11 +385,20 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm8_kernel(GemmP8 p) {
 }
 
 // bf16 [n] -> e4m3 (unit scale): the A operands of the fp8 forward GEMMs that no producer kernel writes directly
-__global__ __launch_bounds__(256) void cast_bf16_fp8_kernel(const bf16* __restrict__ src, uint8_t* __restrict__ dst, int64_t n) {
+__global__ __launch_bounds__(256) void cast_bf16_fp8_kernel(const bf16* __restrict__ src, uint8_t* __restrict__ dst, int64_t n,
+                                                            const uint32_t* __restrict__ a_prev, uint32_t* __restrict__ a_new) {
+  const float s8 = fp8_act_scale(a_prev);        // delayed per-tensor activation scale (1 without a history); a_new: this pass's amax
+  float amax8 = 0.f;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 256 * 8) {
     float v[8];
     Vec8<bf16>::load(src + i, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { amax8 = fmaxf(amax8, fabsf(v[e])); v[e] *= s8; }
     *(i32x2*)(dst + i) = i32x2{(int)fp8_pack4(v), (int)fp8_pack4(v + 4)};
+  }
+  if (a_new) {
+    amax8 = wave_max(amax8);
+    if ((threadIdx.x & 63) == 0) amax_update(a_new, amax8);
   }
 }
 
@@ -500,12 +515,14 @@ struct GemmP8T {
   int tiles_m, tiles_n, splits, accumulate;
   uint32_t a_bytes, b_bytes;
   const uint32_t* a_amax;                    // dY8 = e4m3(dY * s): the accumulator is divided by s
+  const uint32_t* b_amax;                    // X8 = e4m3(X * s_x) (forward activation copy, delayed scale): ... and by s_x; NULL = 1
   // second problem of a PAIR (nbest_wgrad_fp8_pair): output rows >= m_split of the virtual [M][N] result are A2^T . B2 with their own
   // gradient scale (same N and K); m_split = 0: none
   const uint8_t* A2; const uint8_t* B2;
   int64_t lda2, ldb2, m_split;
   uint32_t a2_bytes, b2_bytes;
   const uint32_t* a_amax2;
+  const uint32_t* b_amax2;
 };
 
 __device__ __forceinline__ void stage_tile8t(__amdgpu_buffer_rsrc_t rs, char* tile, int64_t f0, int64_t k0, int64_t ld, int tid) {
@@ -564,7 +581,8 @@ __global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(second ? (void*)p.A2 : (void*)p.A, 0, second ? p.a2_bytes : p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(second ? (void*)p.B2 : (void*)p.B, 0, second ? p.b2_bytes : p.b_bytes, 0x00020000);
   const uint32_t* amaxp = second ? p.a_amax2 : p.a_amax;
-  const float oscale = amaxp ? 1.f / fp8_gscale_of(__uint_as_float(*amaxp)) : 1.f;
+  const uint32_t* bmaxp = second ? p.b_amax2 : p.b_amax;
+  const float oscale = (amaxp ? 1.f / fp8_gscale_of(__uint_as_float(*amaxp)) : 1.f) * (bmaxp ? 1.f / fp8_ascale_of(__uint_as_float(*bmaxp)) : 1.f);
 
   f32x16 acc[TMb][TNb];
 #pragma unroll
@@ -729,8 +747,9 @@ extern "C" size_t nbest_wgrad_fp8_ws_bytes(int64_t M, int64_t N, int64_t K) {
 // dW[M][N] (fp32, ldc) (+)= sum_k dY8[k][M-features] * X8[k][N-features] / s(a_amax); dY8 [K tokens][lda], X8 [K tokens][ldb] e4m3
 // second problem (pair): dY8b / X8b / dWb / Mb rows / its own scale, appended below the first's output tiles
 static int wgrad_fp8_impl(const void* dY8, const void* X8, float* dW, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                          int64_t ldc, const uint32_t* a_amax, const void* dY8b, const void* X8b, float* dWb, int64_t Mb, int64_t ldab,
-                          int64_t ldbb, int64_t ldcb, const uint32_t* a_amaxb, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                          int64_t ldc, const uint32_t* a_amax, const uint32_t* x_amax, const void* dY8b, const void* X8b, float* dWb, int64_t Mb,
+                          int64_t ldab, int64_t ldbb, int64_t ldcb, const uint32_t* a_amaxb, const uint32_t* x_amaxb, int accumulate, void* ws,
+                          size_t ws_bytes, hipStream_t st) {
   const int64_t Mv = M + Mb;     // rows of the virtual output
   GemmP8T p;
   p.A = (const uint8_t*)dY8; p.B = (const uint8_t*)X8; p.C = dW; p.slab = (float*)ws;
@@ -741,14 +760,14 @@ static int wgrad_fp8_impl(const void* dY8, const void* X8, float* dW, int64_t M,
   const int64_t ab = (K - 1) * lda + M, bb = (K - 1) * ldb + N;
   NB_CHECK(ab < ((int64_t)1 << 32) && bb < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "wgrad_fp8: operand larger than 4 GiB");
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
-  p.a_amax = a_amax;
-  p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.m_split = 0; p.a2_bytes = p.b2_bytes = 0; p.a_amax2 = nullptr;
+  p.a_amax = a_amax; p.b_amax = x_amax;
+  p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.m_split = 0; p.a2_bytes = p.b2_bytes = 0; p.a_amax2 = nullptr; p.b_amax2 = nullptr;
   if (Mb > 0) {
     const int64_t ab2 = (K - 1) * ldab + Mb, bb2 = (K - 1) * ldbb + N;
     NB_CHECK(ab2 < ((int64_t)1 << 32) && bb2 < ((int64_t)1 << 32), NBEST_ERR_SHAPE, "wgrad_fp8: operand larger than 4 GiB");
     NB_CHECK(p.splits > 1, NBEST_ERR_SHAPE, "wgrad_fp8_pair: needs a split-K plan");
     p.A2 = (const uint8_t*)dY8b; p.B2 = (const uint8_t*)X8b; p.lda2 = ldab; p.ldb2 = ldbb; p.m_split = M;
-    p.a2_bytes = (uint32_t)ab2; p.b2_bytes = (uint32_t)bb2; p.a_amax2 = a_amaxb;
+    p.a2_bytes = (uint32_t)ab2; p.b2_bytes = (uint32_t)bb2; p.a_amax2 = a_amaxb; p.b_amax2 = x_amaxb;
   }
   if (p.splits > 1) NB_CHECK(ws && ws_bytes >= (size_t)p.splits * Mv * N * sizeof(float), NBEST_ERR_WORKSPACE, "wgrad_fp8: workspace too small");
   constexpr int lds_bytes = 4 * 2 * 256 * BK8;
@@ -766,13 +785,14 @@ static int wgrad_fp8_impl(const void* dY8, const void* X8, float* dW, int64_t M,
 }
 
 extern "C" int nbest_wgrad_fp8(const void* dY8, const void* X8, float* dW, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                               int64_t ldc, const uint32_t* a_amax, int accumulate, void* ws, size_t ws_bytes, nbest_stream_t stream) {
+                               int64_t ldc, const uint32_t* a_amax, const uint32_t* x_amax, int accumulate, void* ws, size_t ws_bytes,
+                               nbest_stream_t stream) {
   NB_CHECK(dY8 && X8 && dW && M > 0 && N > 0 && K > 0, NBEST_ERR_ARG, "wgrad_fp8: bad arguments");
   NB_CHECK(M % 256 == 0 && N % 256 == 0, NBEST_ERR_SHAPE, "wgrad_fp8: output %lld x %lld must be multiples of 256", (long long)M, (long long)N);
   NB_CHECK(lda % 16 == 0 && ldb % 16 == 0 && ldc % 8 == 0 && ((uintptr_t)dY8 & 15) == 0 && ((uintptr_t)X8 & 15) == 0 && ((uintptr_t)dW & 15) == 0,
            NBEST_ERR_ALIGN, "wgrad_fp8: alignment");
-  return wgrad_fp8_impl(dY8, X8, dW, M, N, K, lda, ldb, ldc, a_amax, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, accumulate, ws, ws_bytes,
-                        (hipStream_t)stream);
+  return wgrad_fp8_impl(dY8, X8, dW, M, N, K, lda, ldb, ldc, a_amax, x_amax, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr, accumulate, ws,
+                        ws_bytes, (hipStream_t)stream);
 }
 
 // two fp8 weight gradients with the same K (tokens) and N in one launch (the e4m3 counterpart of nbest_wgrad_pair): the 256 x 256 output
@@ -784,16 +804,16 @@ extern "C" size_t nbest_wgrad_fp8_pair_ws_bytes(int64_t Ma, int64_t Mb, int64_t 
   return sp > 1 ? (size_t)sp * (Ma + Mb) * N * sizeof(float) : 0;
 }
 extern "C" int nbest_wgrad_fp8_pair(const void* dY8a, const void* X8a, float* dWa, int64_t Ma, int64_t lda_a, int64_t ldb_a, int64_t ldc_a,
-                                    const uint32_t* amax_a, const void* dY8b, const void* X8b, float* dWb, int64_t Mb, int64_t lda_b,
-                                    int64_t ldb_b, int64_t ldc_b, const uint32_t* amax_b, int64_t N, int64_t K, int accumulate, void* ws,
-                                    size_t ws_bytes, nbest_stream_t stream) {
+                                    const uint32_t* amax_a, const uint32_t* xamax_a, const void* dY8b, const void* X8b, float* dWb, int64_t Mb,
+                                    int64_t lda_b, int64_t ldb_b, int64_t ldc_b, const uint32_t* amax_b, const uint32_t* xamax_b, int64_t N,
+                                    int64_t K, int accumulate, void* ws, size_t ws_bytes, nbest_stream_t stream) {
   NB_CHECK(dY8a && X8a && dWa && dY8b && X8b && dWb && N > 0 && K > 0, NBEST_ERR_ARG, "wgrad_fp8_pair: bad arguments");
   NB_CHECK(nbest_wgrad_fp8_pair_ws_bytes(Ma, Mb, N, K) > 0, NBEST_ERR_SHAPE, "wgrad_fp8_pair: Ma, Mb, N must be multiples of 256 and the pair must split K");
   NB_CHECK(lda_a % 16 == 0 && ldb_a % 16 == 0 && ldc_a % 8 == 0 && lda_b % 16 == 0 && ldb_b % 16 == 0 && ldc_b % 8 == 0 &&
                (((uintptr_t)dY8a | (uintptr_t)X8a | (uintptr_t)dWa | (uintptr_t)dY8b | (uintptr_t)X8b | (uintptr_t)dWb) & 15) == 0,
            NBEST_ERR_ALIGN, "wgrad_fp8_pair: alignment");
-  return wgrad_fp8_impl(dY8a, X8a, dWa, Ma, N, K, lda_a, ldb_a, ldc_a, amax_a, dY8b, X8b, dWb, Mb, lda_b, ldb_b, ldc_b, amax_b, accumulate, ws,
-                        ws_bytes, (hipStream_t)stream);
+  return wgrad_fp8_impl(dY8a, X8a, dWa, Ma, N, K, lda_a, ldb_a, ldc_a, amax_a, xamax_a, dY8b, X8b, dWb, Mb, lda_b, ldb_b, ldc_b, amax_b, xamax_b,
+                        accumulate, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // tile width gemm8_kernel uses for an [N][K] e4m3 weight at training-size token counts (its wn rule at M = 32 768)
@@ -809,13 +829,16 @@ extern "C" int nbest_pack_weights_fp8(const void* src, void* dst, const nbest_ma
   return NBEST_OK;
 }
 
-extern "C" int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream) {
+int nbest_internal_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, const uint32_t* a_prev, uint32_t* a_new, hipStream_t st) {
   NB_CHECK(src && dst && n > 0 && n % 8 == 0, NBEST_ERR_ARG, "cast_bf16_to_fp8: bad arguments");
   int64_t g = (n / 8 + 255) / 256;
   if (g > 4096) g = 4096;
-  cast_bf16_fp8_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>((const bf16*)src, (uint8_t*)dst, n);
+  cast_bf16_fp8_kernel<<<(int)g, 256, 0, st>>>((const bf16*)src, (uint8_t*)dst, n, a_prev, a_new);
   NB_LAUNCH_CHECK();
   return NBEST_OK;
+}
+extern "C" int nbest_cast_bf16_to_fp8(const void* src, void* dst, int64_t n, nbest_stream_t stream) {
+  return nbest_internal_cast_bf16_to_fp8(src, dst, n, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int nbest_quantize_weights_fp8(const float* master, void* w8, void* w8t, const nbest_matrix_desc* descs, int n_matrices,
@@ -895,6 +918,7 @@ extern "C" int nbest_gemm_fp8(const nbest_gemm_fp8_args* a, nbest_stream_t strea
   p.out_scale = a->out_scale;
   p.out_scale_dev = a->out_scale_dev;
   p.a_amax = a->a_amax;
+  // DGELU: C8 = scaled e4m3 copy of the gradient; BIAS_GELU: p.C8 = e4m3 copy of gelu(u), scaled the same way when a history is given
   p.c8g = Fp8Grad{epi == NBEST_EPI_DGELU ? (uint8_t*)a->C8 : nullptr, a->c8_amax_prev, a->c8_amax_new};
   p.colpart = (epi == NBEST_EPI_DGELU && a->colsum_out) ? (float*)a->ws : nullptr;
   p.drop = make_drop(a->drop_p, a->seed, a->drop_stream);

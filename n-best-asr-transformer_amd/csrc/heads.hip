@@ -1,8 +1,9 @@
 // K7 STC heads + losses (forward and analytic backward), K8 CLS-MSE, K10 decode.
 //
-// Shapes are tiny (B x 171 x 768 for bert-base on DSTC2), so everything is fp32 VALU work in a
-// handful of launches; the point is to replace ~40 tiny launches + 4 host syncs of the reference
-// (/root/reference/n_best_asr_bert.py:160-195) and to hand dCLS to the encoder backward.
+// Shapes are tiny (B x 171 x 768 for bert-base on DSTC2), so everything is fp32 VALU work in two launches
+// (heads_fwd_kernel, heads_bwd_kernel); the point is to replace ~40 tiny launches + 4 host syncs of the reference
+// (/root/reference/models/modules/hierarchical_classifier.py:35-60, /root/reference/n_best_asr_bert.py:160-195) and to hand
+// dCLS to the encoder backward.
 //
 // Workspace layout (floats): cls[B][H] | logits[B][R] | dz[B][R] | sample_loss[B][4]
 #include "common.h"
@@ -47,87 +48,79 @@ __device__ __forceinline__ void heads_mask_words(const DropCfg& drop, int lay, i
   }
 }
 
-// logits[b][r] = sum_h Wh[r][h] * drop_{layer(r)}(cls[b][h]) + bh[r];  grid (B, kLogitSplit), block 256:
-// blockIdx.y owns a contiguous slice of the head rows (more, shorter blocks: the kernel is latency bound).  A block hashes the
-// masks of the layers its rows belong to into LDS; the blockIdx.y == 0 block of a sample hashes all of them and also writes
-// them to `mw` for the two gradient kernels.
-constexpr int kLogitSplit = 8;
-// (Measured: 1024-thread blocks make the three GEMV-like kernels of the heads slower - 67 / 33 / 48 us against 46 / 39 / 29.)
-constexpr int kHeadsThreads = 256;
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ sample_loss, int B, float* __restrict__ out) {
+  __shared__ float sm[16];
+  for (int k = 0; k < 4; ++k) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) s += sample_loss[4 * b + k];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) out[k] = s;
+  }
+}
+
+// ---- round 4: the heads as TWO launches (147 us in four launches for a 256 x 768 x 171 problem) ------------------
+// heads_fwd_kernel: one block per sample does what heads_logits_kernel + heads_scores_kernel did - CLS row and the layers' dropout bits
+// into LDS, the 171 logits (a wave per row), then scores / losses / d(loss)/d(logits) with the TOP labels spread over the waves (the
+// old scores kernel walked the 30 tops one after the other in a single wave: 37 us of dependent exp / log / shuffle latency).
+// heads_bwd_kernel: weight gradient and input gradient in one grid (blocks [0, nW): an 8-row x 64-column tile of dWh, waves split the
+// batch, the CLS column chunk loaded once per sample for all 8 rows; blocks [nW, nW + nD): 8 samples x 64 columns of dCLS, waves split
+// the head rows, the weight element loaded once for all 8 samples); the last block sums the per-sample losses.  Fixed-order sums.
+constexpr int kFwdThreads = 512;
 template <typename T>
-__global__ __launch_bounds__(kHeadsThreads) void heads_logits_kernel(const T* __restrict__ hidden, int64_t cls_stride,
-                                                           const float* __restrict__ Wh, const float* __restrict__ bh,
-                                                           const int32_t* __restrict__ head_row, int n_top, int R, int H,
-                                                           float* __restrict__ cls_out, float* __restrict__ logits,
-                                                           uint32_t* __restrict__ mw, int32_t* __restrict__ lay_row, int n_lay,
-                                                           DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];  // [H] | mask words [n_lay][W] | layer of row [R]
+__global__ __launch_bounds__(kFwdThreads) void heads_fwd_kernel(const T* __restrict__ hidden, int64_t cls_stride, const float* __restrict__ Wh,
+                                                                 const float* __restrict__ bh, const float* __restrict__ labels,
+                                                                 const int32_t* __restrict__ bottom_off, const int32_t* __restrict__ bottom_ids,
+                                                                 const int32_t* __restrict__ head_row, int n_top, int n_bottom, int R, int H,
+                                                                 int n_heads, int n_lay, float* __restrict__ cls_out, float* __restrict__ top,
+                                                                 float* __restrict__ bott, float* __restrict__ fin, float* __restrict__ dz,
+                                                                 float* __restrict__ sample_loss, uint32_t* __restrict__ mw,
+                                                                 int32_t* __restrict__ lay_row, DropCfg drop) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [H] | logits [R] | layer of row [R] | mask words [n_lay][W] | loss partials [waves][3]
   const int b = blockIdx.x, B = gridDim.x, W = (H + 31) >> 5;
-  uint32_t* mk = (uint32_t*)(xs + H);
-  int32_t* lay_s = (int32_t*)(mk + n_lay * W);
+  float* zs = xs + H;
+  int32_t* lay_s = (int32_t*)(zs + R);
+  uint32_t* mk = (uint32_t*)(lay_s + R);
+  float* lsum = (float*)(mk + n_lay * W);
   const T* x = hidden + (int64_t)b * cls_stride;
   for (int h = threadIdx.x; h < H; h += blockDim.x) {
     const float v = to_f<T>(x[h]);
     xs[h] = v;
-    if (blockIdx.y == 0) cls_out[(int64_t)b * H + h] = v;
+    cls_out[(int64_t)b * H + h] = v;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int per = (R + gridDim.y - 1) / gridDim.y;
-  const int r0 = blockIdx.y * per, r1 = (r0 + per < R) ? r0 + per : R;
-  // layer_of_row walks head_row with dependent loads (microseconds): once per row, all rows in parallel, then LDS lookups; the
-  // first block also publishes the table for the gradient kernels
-  const bool first = (blockIdx.x == 0 && blockIdx.y == 0);
-  for (int r = (first ? 0 : r0) + (int)threadIdx.x; r < (first ? R : r1); r += blockDim.x) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
     const int l = layer_of_row(r, head_row, n_top, nullptr);
     lay_s[r] = l;
-    if (first) lay_row[r] = l;
+    if (b == 0) lay_row[r] = l;
   }
+  if (drop.thr16)
+    for (int lay = 0; lay < n_lay; ++lay) heads_mask_words(drop, lay, b, B, H, W, mk + lay * W, mw + ((int64_t)lay * B + b) * W);
   __syncthreads();
-  if (drop.thr16) {
-    const bool all = (blockIdx.y == 0);
-    const int la = all ? 0 : (r0 < r1 ? lay_s[r0] : 0);
-    const int lb = all ? n_lay - 1 : (r0 < r1 ? lay_s[r1 - 1] : -1);
-    for (int lay = la; lay <= lb; ++lay)
-      heads_mask_words(drop, lay, b, B, H, W, mk + lay * W, all ? mw + ((int64_t)lay * B + b) * W : nullptr);
-  }
-  __syncthreads();
-  for (int r = r0 + wave; r < r1; r += nw) {
-    const int lay = lay_s[r];
+  for (int r = wave; r < R; r += nw) {
     const float* w = Wh + (int64_t)r * H;
-    const uint32_t* mrow = mk + lay * W;
+    const uint32_t* mrow = mk + lay_s[r] * W;
     float s = 0.f;
-#pragma unroll 16
+#pragma unroll 4
     for (int h = lane; h < H; h += 64) {
       float xv = xs[h];
       if (drop.thr16) xv = ((mrow[h >> 5] >> (h & 31)) & 1u) ? xv * drop.scale : 0.f;
       s = fmaf(w[h], xv, s);
     }
     s = wave_sum(s);
-    if (lane == 0) logits[(int64_t)b * R + r] = s + bh[r];
+    if (lane == 0) zs[r] = s + bh[r];
   }
-}
-
-// per sample: scores, losses and d(loss)/d(logits).  grid B, block 64 (one wave; n_top, head sizes small)
-__global__ __launch_bounds__(64) void heads_scores_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
-                                                          const int32_t* __restrict__ bottom_off, const int32_t* __restrict__ bottom_ids,
-                                                          const int32_t* __restrict__ head_row, int n_top, int n_bottom, int R,
-                                                          int n_heads, float* __restrict__ top, float* __restrict__ bott,
-                                                          float* __restrict__ fin, float* __restrict__ dz,
-                                                          float* __restrict__ sample_loss) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const float* z = logits + (int64_t)b * R;
+  __syncthreads();
+  const float* z = zs;
   const float* y = labels + (int64_t)b * n_bottom;
   float l_bot = 0.f, l_top = 0.f, l_ce = 0.f;
-  // top labels are processed one per iteration by the whole wave (lanes parallelise the head columns)
-  for (int t = 0; t < n_top; ++t) {
+  for (int t = wave; t < n_top; t += nw) {                  // a wave per top label (lanes parallelise the head columns)
     const int o0 = bottom_off[t], nk = bottom_off[t + 1] - o0, hr = head_row[t];
     const float zt = z[t];
     const float pt = 1.0f / (1.0f + __expf(-zt));
     float dpt = 0.f;  // d(loss)/d(top score)
     float ytop = 0.f;
     if (hr < 0) {
-      // single bottom label: final = top score
-      const int bi = bottom_ids[o0];
+      const int bi = bottom_ids[o0];                        // single bottom label: final = top score
       const float yy = y[bi];
       ytop = yy;
       if (lane == 0) {
@@ -136,27 +129,24 @@ __global__ __launch_bounds__(64) void heads_scores_kernel(const float* __restric
       }
       dpt += (pt - yy) / fmaxf(pt * (1.f - pt), 1e-12f);
     } else {
-      // softmax head over nk columns (nk may exceed 64: strided)
-      float mx = -INFINITY;
+      float mx = -INFINITY;                                 // softmax head over nk columns (nk may exceed 64: strided)
       for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, z[hr + j]);
       mx = wave_max(mx);
       float se = 0.f;
       for (int j = lane; j < nk; j += 64) se += __expf(z[hr + j] - mx);
       se = wave_sum(se);
       const float inv = 1.0f / se;
-      // class index: position of the active bottom label, else the last column (NONE)
-      int idx = nk - 1;
+      int idx = nk - 1;                                     // class index: the active bottom label, else the last column (NONE)
       float ysum = 0.f;
       for (int j = lane; j < nk; j += 64) {
         const float yy = y[bottom_ids[o0 + j]];
         ysum += yy;
-        if (yy > 0.5f) idx = min(idx, j);   // STC_util asserts at most one hot: first == the one
+        if (yy > 0.5f) idx = min(idx, j);
       }
       ysum = wave_sum(ysum);
       for (int o = 32; o > 0; o >>= 1) idx = min(idx, __shfl_xor(idx, o, 64));
       if (ysum == 0.f) idx = nk - 1;
       ytop = ysum;
-      // pass 1: ds_j and sum_j ds_j s_j ; bottom BCE ; gradient wrt top through final = pt * s_j
       float dot = 0.f, dtop_acc = 0.f, lb = 0.f;
       for (int j = lane; j < nk; j += 64) {
         const float s = __expf(z[hr + j] - mx) * inv;
@@ -189,8 +179,7 @@ __global__ __launch_bounds__(64) void heads_scores_kernel(const float* __restric
         dz[(int64_t)b * R + hr + j] = s * (ds - dot);
       }
     }
-    // top BCE against y . B2T
-    if (lane == 0) l_top += -(ytop * fmaxf(logf(pt), -100.f) + (1.f - ytop) * fmaxf(logf(1.f - pt), -100.f));
+    if (lane == 0) l_top += -(ytop * fmaxf(logf(pt), -100.f) + (1.f - ytop) * fmaxf(logf(1.f - pt), -100.f));   // top BCE against y . B2T
     dpt += (pt - ytop) / fmaxf(pt * (1.f - pt), 1e-12f);
     if (lane == 0) {
       top[(int64_t)b * n_top + t] = pt;
@@ -198,96 +187,146 @@ __global__ __launch_bounds__(64) void heads_scores_kernel(const float* __restric
     }
   }
   l_ce = wave_sum(l_ce);
-  if (lane == 0) {
-    sample_loss[4 * b + 0] = l_bot;
-    sample_loss[4 * b + 1] = l_top;
-    sample_loss[4 * b + 2] = l_ce;
-    sample_loss[4 * b + 3] = 0.f;
+  if (lane == 0) { lsum[3 * wave] = l_bot; lsum[3 * wave + 1] = l_top; lsum[3 * wave + 2] = l_ce; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float v = 0.f;
+    for (int w = 0; w < nw; ++w) v += lsum[3 * w + threadIdx.x];     // wave order: the same sum on every run
+    sample_loss[4 * b + threadIdx.x] = v;
   }
+  if (threadIdx.x == 3) sample_loss[4 * b + 3] = 0.f;
 }
 
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ sample_loss, int B, float* __restrict__ out) {
+constexpr int kBwdRows = 8;      // head rows (wgrad) / samples (dgrad) per block
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ cls, const float* __restrict__ dz, const float* __restrict__ Wh,
+                                                        int B, int R, int H, float* __restrict__ dWh, float* __restrict__ dbh,
+                                                        float* __restrict__ dcls, int accumulate, const uint32_t* __restrict__ mw,
+                                                        const int32_t* __restrict__ lay_row, DropCfg drop, const float* __restrict__ sample_loss,
+                                                        float* __restrict__ loss_out, int nW) {
+  __shared__ float red[4][kBwdRows][64];
+  __shared__ float redb[4][kBwdRows];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nh = (H + 63) >> 6, W = (H + 31) >> 5;
+  const int bid = blockIdx.x;
+  if (bid < nW) {
+    // ---- dWh[r][h] = sum_b dz[b][r] * drop_{layer(r)}(cls[b][h]); dbh[r] = sum_b dz[b][r] ----
+    const int r0 = (bid / nh) * kBwdRows, h = (bid % nh) * 64 + lane;
+    const bool hv = h < H;
+    int lay[kBwdRows];
+#pragma unroll
+    for (int j = 0; j < kBwdRows; ++j) lay[j] = lay_row[min(r0 + j, R - 1)];
+    float acc[kBwdRows], sb[kBwdRows];
+#pragma unroll
+    for (int j = 0; j < kBwdRows; ++j) acc[j] = sb[j] = 0.f;
+    for (int b = wave; b < B; b += 4) {
+      const float xv = hv ? cls[(int64_t)b * H + h] : 0.f;
+      const float xd = xv * drop.scale;
+#pragma unroll
+      for (int j = 0; j < kBwdRows; ++j) {
+        const float g = (r0 + j < R) ? dz[(int64_t)b * R + r0 + j] : 0.f;
+        float xm = xv;
+        if (drop.thr16) xm = (hv && ((mw[((int64_t)lay[j] * B + b) * W + (h >> 5)] >> (h & 31)) & 1u)) ? xd : 0.f;
+        acc[j] = fmaf(g, xm, acc[j]);
+        sb[j] += g;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBwdRows; ++j) {
+      red[wave][j][lane] = acc[j];
+      if (lane == 0) redb[wave][j] = sb[j];
+    }
+    __syncthreads();
+    for (int j = wave; j < kBwdRows; j += 4) {
+      const int r = r0 + j;
+      if (r < R && hv) {
+        const float v = (red[0][j][lane] + red[1][j][lane]) + (red[2][j][lane] + red[3][j][lane]);
+        float* o = dWh + (int64_t)r * H + h;
+        *o = accumulate ? *o + v : v;
+      }
+      if (r < R && lane == 0 && (bid % nh) == 0) {
+        const float v = (redb[0][j] + redb[1][j]) + (redb[2][j] + redb[3][j]);
+        dbh[r] = accumulate ? dbh[r] + v : v;
+      }
+    }
+    return;
+  }
+  const int nD = ((B + kBwdRows - 1) / kBwdRows) * nh;
+  if (bid < nW + nD) {
+    // ---- dcls[b][h] = sum_r dz[b][r] * Wh[r][h] * dropmask_{layer(r)}(b, h) ----
+    const int q = bid - nW, b0 = (q / nh) * kBwdRows, h = (q % nh) * 64 + lane;
+    const bool hv = h < H;
+    float acc[kBwdRows];
+#pragma unroll
+    for (int j = 0; j < kBwdRows; ++j) acc[j] = 0.f;
+    for (int r = wave; r < R; r += 4) {
+      const float w = hv ? Wh[(int64_t)r * H + h] : 0.f;
+      const float wd = w * drop.scale;
+      const int lay = lay_row[r];
+#pragma unroll
+      for (int j = 0; j < kBwdRows; ++j) {
+        const int b = min(b0 + j, B - 1);
+        const float g = dz[(int64_t)b * R + r];
+        float wm = w;
+        if (drop.thr16) wm = (hv && ((mw[((int64_t)lay * B + b) * W + (h >> 5)] >> (h & 31)) & 1u)) ? wd : 0.f;
+        acc[j] = fmaf(g, wm, acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBwdRows; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    for (int j = wave; j < kBwdRows; j += 4) {
+      const int b = b0 + j;
+      if (b < B && hv) dcls[(int64_t)b * H + h] = (red[0][j][lane] + red[1][j][lane]) + (red[2][j][lane] + red[3][j][lane]);
+    }
+    return;
+  }
+  // ---- last block (launched only with loss_out): the four loss sums over the batch (fixed order) ----
+  if (!loss_out) return;
   __shared__ float sm[16];
   for (int k = 0; k < 4; ++k) {
     float s = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) s += sample_loss[4 * b + k];
     s = block_sum(s, sm);
-    if (threadIdx.x == 0) out[k] = s;
+    if (threadIdx.x == 0) loss_out[k] = s;
   }
 }
 
-// dWh[r][h] = sum_b dz[b][r] * drop(cls[b][h]); dbh[r] = sum_b dz[b][r].  grid (R, ceil(H/64)), block 256:
-// a block owns one head row x 64 columns (lane = column), its waves split the batch.  Fixed-order LDS reduce (deterministic).
-__global__ __launch_bounds__(kHeadsThreads) void heads_wgrad_kernel(const float* __restrict__ cls, const float* __restrict__ dz,
-                                                          const int32_t* __restrict__ head_row, int n_top, int B, int R, int H,
-                                                          float* __restrict__ dWh, float* __restrict__ dbh, int accumulate,
-                                                          const uint32_t* __restrict__ mw, const int32_t* __restrict__ lay_row,
-                                                          DropCfg drop) {
-  __shared__ float red[kHeadsThreads / 64][64];
-  __shared__ float redb[kHeadsThreads / 64];
-  const int r = blockIdx.x, h = blockIdx.y * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int lay = lay_row[r];
-  const int W = (H + 31) >> 5;
-  const uint32_t* mcol = mw + (int64_t)lay * B * W + (h >> 5);   // the layer's mask bits of column h: one word per sample
-  float acc = 0.f, sb = 0.f;
-  if (h < H) {
-#pragma unroll 16
-    for (int b = wave; b < B; b += nw) {
-      const float g = dz[(int64_t)b * R + r];
-      float xv = cls[(int64_t)b * H + h];
-      if (drop.thr16) xv = ((mcol[(int64_t)b * W] >> (h & 31)) & 1u) ? xv * drop.scale : 0.f;
-      acc = fmaf(g, xv, acc);
-      sb += g;
+// d(logits) from ARBITRARY upstream gradients of the three outputs (the autograd bridge: the reference's loop calls
+// total_loss.backward() on whatever it built from top / bottoms / final, /root/reference/n_best_asr_bert.py:255-264):
+//   final[b][bi] = top_t (single-bottom top) | top_t * s_j ;  s = softmax(head logits) ;  top = sigmoid(z_t)
+// grid B, block 256: a wave per top label, lanes over the head columns (as heads_fwd_kernel).
+__global__ __launch_bounds__(256) void heads_vjp_dz_kernel(const float* __restrict__ top, const float* __restrict__ bott,
+                                                           const float* __restrict__ dtop, const float* __restrict__ dbott,
+                                                           const float* __restrict__ dfin, const int32_t* __restrict__ bottom_off,
+                                                           const int32_t* __restrict__ bottom_ids, const int32_t* __restrict__ head_row,
+                                                           int n_top, int n_bottom, int R, float* __restrict__ dz) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const float* gf = dfin + (int64_t)b * n_bottom;
+  for (int t = wave; t < n_top; t += nw) {
+    const int o0 = bottom_off[t], nk = bottom_off[t + 1] - o0, hr = head_row[t];
+    const float pt = top[(int64_t)b * n_top + t];
+    float dpt = dtop[(int64_t)b * n_top + t];
+    if (hr < 0) {
+      dpt += gf[bottom_ids[o0]];
+    } else {
+      const float* sb = bott + (int64_t)b * (R - n_top) + (hr - n_top);
+      const float* gb = dbott + (int64_t)b * (R - n_top) + (hr - n_top);
+      float dot = 0.f, acc = 0.f;
+      for (int j = lane; j < nk; j += 64) {
+        const float s = sb[j], g = gf[bottom_ids[o0 + j]];
+        const float ds = gb[j] + g * pt;
+        dot += ds * s;
+        acc += g * s;
+      }
+      dot = wave_sum(dot);
+      dpt += wave_sum(acc);
+      for (int j = lane; j < nk; j += 64) {
+        const float s = sb[j];
+        const float ds = gb[j] + gf[bottom_ids[o0 + j]] * pt;
+        dz[(int64_t)b * R + hr + j] = s * (ds - dot);
+      }
     }
-  }
-  red[wave][threadIdx.x & 63] = acc;
-  if ((threadIdx.x & 63) == 0) redb[wave] = sb;
-  __syncthreads();
-  if (wave == 0 && h < H) {
-    const int l = threadIdx.x;
-    float v = 0.f;
-    for (int w = 0; w < nw; ++w) v += red[w][l];
-    float* o = dWh + (int64_t)r * H + h;
-    *o = accumulate ? *o + v : v;
-  }
-  if (threadIdx.x == 0 && blockIdx.y == 0) {
-    float v = 0.f;
-    for (int w = 0; w < nw; ++w) v += redb[w];
-    dbh[r] = accumulate ? dbh[r] + v : v;
-  }
-}
-
-// dcls[b][h] = sum_r dz[b][r] * Wh[r][h] * dropmask_{layer(r)}(b,h).  grid (B, ceil(H/64)), block 256: waves split r
-__global__ __launch_bounds__(kHeadsThreads) void heads_dgrad_kernel(const float* __restrict__ Wh, const float* __restrict__ dz,
-                                                          const int32_t* __restrict__ head_row, int n_top, int R, int H,
-                                                          float* __restrict__ dcls, const uint32_t* __restrict__ mw,
-                                                          const int32_t* __restrict__ lay_row, DropCfg drop) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // dz row [R] | layer of row [R] | red [waves][64]
-  const int b = blockIdx.x, B = gridDim.x;
-  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, h = blockIdx.y * 64 + l, nw = blockDim.x >> 6;
-  float* red = sh + 2 * R;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) {
-    sh[r] = dz[(int64_t)b * R + r];
-    sh[R + r] = (float)lay_row[r];
-  }
-  __syncthreads();
-  float s = 0.f;
-  const int W = (H + 31) >> 5;
-  const uint32_t* mcol = mw + (int64_t)b * W + (h >> 5);       // this sample's mask bits of column h: one word per layer
-  if (h < H) {
-#pragma unroll 16
-    for (int r = wave; r < R; r += nw) {
-      float w = Wh[(int64_t)r * H + h];
-      if (drop.thr16) w = ((mcol[(int64_t)(int)sh[R + r] * B * W] >> (h & 31)) & 1u) ? w * drop.scale : 0.f;
-      s = fmaf(sh[r], w, s);
-    }
-  }
-  red[wave * 64 + l] = s;
-  __syncthreads();
-  if (wave == 0 && h < H) {
-    float v = 0.f;
-    for (int w = 0; w < nw; ++w) v += red[w * 64 + l];
-    dcls[(int64_t)b * H + h] = v;
+    if (lane == 0) dz[(int64_t)b * R + t] = dpt * pt * (1.f - pt);
   }
 }
 
@@ -367,24 +406,50 @@ extern "C" int nbest_stc_heads(const void* hidden, int64_t cls_stride, const flo
   const int n_heads = R - n_bottom;
   NB_CHECK(n_heads > 0, NBEST_ERR_SHAPE, "stc_heads: label space has no multi-value head");
   const int n_lay = n_heads + 1;
-  const size_t smemH = (size_t)H * sizeof(float) + (size_t)n_lay * ((H + 31) / 32) * sizeof(uint32_t) + (size_t)R * sizeof(int32_t);
-  if (dtype == NBEST_F32)
-    heads_logits_kernel<float><<<dim3(B, kLogitSplit), kHeadsThreads, smemH, st>>>((const float*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, mw, lay_row, n_lay, d);
-  else if (dtype == NBEST_BF16)
-    heads_logits_kernel<bf16><<<dim3(B, kLogitSplit), kHeadsThreads, smemH, st>>>((const bf16*)hidden, cls_stride, Wh, bh, ls->head_row, n_top, R, H, cls, logits, mw, lay_row, n_lay, d);
+  const size_t smemF = ((size_t)H + 2 * (size_t)R) * sizeof(float) + (size_t)n_lay * ((H + 31) / 32) * sizeof(uint32_t) + (size_t)3 * (kFwdThreads / 64) * sizeof(float);
+#define NB_HEADS_FWD(TT)                                                                                                              \
+  heads_fwd_kernel<TT><<<B, kFwdThreads, smemF, st>>>((const TT*)hidden, cls_stride, Wh, bh, labels, ls->bottom_off, ls->bottom_ids,      \
+                                                      ls->head_row, n_top, n_bottom, R, H, n_heads, n_lay, cls, top, bott, final_scores,  \
+                                                      dz, sloss, mw, lay_row, d)
+  if (dtype == NBEST_F32) NB_HEADS_FWD(float);
+  else if (dtype == NBEST_BF16) NB_HEADS_FWD(bf16);
   else NB_CHECK(false, NBEST_ERR_DTYPE, "stc_heads: bad dtype %d", dtype);
+#undef NB_HEADS_FWD
   NB_LAUNCH_CHECK();
-  heads_scores_kernel<<<B, 64, 0, st>>>(logits, labels, ls->bottom_off, ls->bottom_ids, ls->head_row, n_top, n_bottom, R,
-                                       n_heads, top, bott, final_scores, dz, sloss);
-  NB_LAUNCH_CHECK();
-  loss_reduce_kernel<<<1, 256, 0, st>>>(sloss, B, loss_parts);
-  NB_LAUNCH_CHECK();
+  (void)logits;
   if (need_grad) {
-    heads_wgrad_kernel<<<dim3(R, (H + 63) / 64), kHeadsThreads, 0, st>>>(cls, dz, ls->head_row, n_top, B, R, H, dWh, dbh, accumulate, mw, lay_row, d);
-    NB_LAUNCH_CHECK();
-    heads_dgrad_kernel<<<dim3(B, (H + 63) / 64), kHeadsThreads, ((size_t)2 * R + kHeadsThreads) * sizeof(float), st>>>(Wh, dz, ls->head_row, n_top, R, H, dcls, mw, lay_row, d);
-    NB_LAUNCH_CHECK();
+    const int nh = (H + 63) / 64;
+    const int nW = ((R + kBwdRows - 1) / kBwdRows) * nh, nD = ((B + kBwdRows - 1) / kBwdRows) * nh;
+    heads_bwd_kernel<<<nW + nD + 1, 256, 0, st>>>(cls, dz, Wh, B, R, H, dWh, dbh, dcls, accumulate, mw, lay_row, d, sloss, loss_parts, nW);
+  } else {
+    loss_reduce_kernel<<<1, 256, 0, st>>>(sloss, B, loss_parts);
   }
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
+// Backward of the heads for arbitrary upstream gradients (autograd bridge; hipabi.stc_heads_vjp): `ws` is the workspace a
+// nbest_stc_heads call with the same (hidden, Wh, dropout seed) just used - it still holds the fp32 CLS rows, the layers' dropout bits
+// and the row -> layer table.  dcls [B][H] is overwritten; dWh / dbh are overwritten unless accumulate.
+extern "C" int nbest_stc_heads_vjp(const float* Wh, const nbest_label_space* ls, const float* top, const float* bott, const float* dtop,
+                                   const float* dbott, const float* dfin, float* dcls, float* dWh, float* dbh, int B, int H, int accumulate,
+                                   float drop_p, uint64_t seed, uint32_t drop_stream, void* ws, size_t ws_bytes, nbest_stream_t stream) {
+  NB_CHECK(Wh && ls && top && bott && dtop && dbott && dfin && dcls && dWh && dbh && ws && B > 0 && H > 0, NBEST_ERR_ARG, "stc_heads_vjp: null pointer");
+  const int R = ls->n_rows, n_top = ls->n_top, n_bottom = ls->n_bottom;
+  NB_CHECK(ws_bytes >= nbest_heads_ws_bytes(B, R, H), NBEST_ERR_WORKSPACE, "stc_heads_vjp: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* cls = (float*)ws;
+  float* dz = cls + (size_t)B * H + (size_t)B * R;
+  float* sloss = dz + (size_t)B * R;
+  uint32_t* mw = (uint32_t*)(sloss + (size_t)4 * B);
+  int32_t* lay_row = (int32_t*)(mw + (size_t)(R + 1) * B * ((H + 31) / 32));
+  const DropCfg d = make_drop(drop_p, seed, drop_stream);
+  heads_vjp_dz_kernel<<<B, 256, 0, st>>>(top, bott, dtop, dbott, dfin, ls->bottom_off, ls->bottom_ids, ls->head_row, n_top, n_bottom, R, dz);
+  NB_LAUNCH_CHECK();
+  const int nh = (H + 63) / 64;
+  const int nW = ((R + kBwdRows - 1) / kBwdRows) * nh, nD = ((B + kBwdRows - 1) / kBwdRows) * nh;
+  heads_bwd_kernel<<<nW + nD, 256, 0, st>>>(cls, dz, Wh, B, R, H, dWh, dbh, dcls, accumulate, mw, lay_row, d, nullptr, nullptr, nW);
+  NB_LAUNCH_CHECK();
   return NBEST_OK;
 }
 

@@ -77,7 +77,12 @@ template <int VPL>
 __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, bf16* __restrict__ y,
                                                           float* __restrict__ stats, int64_t M, float eps,
-                                                          uint8_t* __restrict__ y8) {   // optional e4m3 copy of y (fp8 forward)
+                                                          uint8_t* __restrict__ y8,      // optional e4m3 copy of y (fp8 forward):
+                                                          const uint32_t* __restrict__ a_prev, uint32_t* __restrict__ a_new) {
+  // y8 = e4m3(y * s), s = 2^floor(log2(224 / amax)) from the amax y had in the previous pass (delayed scaling, common.h
+  // fp8_ascale_of); this pass's amax goes to a_new.  Both null: unit scale.
+  const float s8 = fp8_act_scale(a_prev);
+  float amax8 = 0.f;
   constexpr int H = VPL * 256;
   constexpr float invH = 1.0f / (float)H;
   const int lane = threadIdx.x & 63;
@@ -121,13 +126,18 @@ __global__ __launch_bounds__(256) void ln_fwd_fast_kernel(const bf16* __restrict
       const f32x2 o0 = v[i][0] * rstd * gm[i][0] + bt[i][0], o1 = v[i][1] * rstd * gm[i][1] + bt[i][1];
       const uint2 pk = uint2{pack2(o0), pack2(o1)};
       *(uint2*)(y + row * H + 4 * (lane + 64 * i)) = pk;
-      if (y8) {   // e4m3 of the bf16 value that was just stored (what a cast of y would give)
+      if (y8) {   // e4m3 of the bf16 value that was just stored (what a cast of y would give), times the tensor's scale
         const f32x2 r0 = unpack2(pk.x), r1 = unpack2(pk.y);
-        const float q[4] = {r0[0], r0[1], r1[0], r1[1]};
+        if (a_new) amax8 = fmaxf(fmaxf(amax8, fmaxf(fabsf(r0[0]), fabsf(r0[1]))), fmaxf(fabsf(r1[0]), fabsf(r1[1])));
+        const float q[4] = {r0[0] * s8, r0[1] * s8, r1[0] * s8, r1[1] * s8};
         *(uint32_t*)(y8 + row * H + 4 * (lane + 64 * i)) = fp8_pack4(q);
       }
     }
     if (lane == 0) *(f32x2*)(stats + 2 * row) = f32x2{mean, rstd};
+  }
+  if (y8 && a_new) {
+    amax8 = wave_max(amax8);
+    if (lane == 0) amax_update(a_new, amax8);
   }
 }
 
@@ -997,7 +1007,7 @@ extern "C" size_t nbest_embed_bwd_ws_bytes(int64_t M, int64_t H) {
 
 // y8 != NULL (bf16, H % 256 == 0, H <= 1024 only): also write the e4m3 copy of y that the next fp8 forward GEMM reads
 int nbest_internal_layernorm_fwd8(const void* x, const float* gamma, const float* beta, void* y, void* y8, float* stats,
-                                  int64_t M, int H, float eps, int dtype, nbest_stream_t stream) {
+                                  int64_t M, int H, float eps, int dtype, nbest_stream_t stream, const uint32_t* a_prev, uint32_t* a_new) {
   if (int e = check_h(H)) return e;
   NB_CHECK(x && gamma && beta && y && stats && M > 0, NBEST_ERR_ARG, "layernorm_fwd: null pointer or M <= 0");
   NB_CHECK(!y8 || (dtype == NBEST_BF16 && H % 256 == 0 && H <= 1024), NBEST_ERR_SHAPE, "layernorm_fwd: fp8 copy needs bf16 and H in {256..1024}");
@@ -1008,10 +1018,10 @@ int nbest_internal_layernorm_fwd8(const void* x, const float* gamma, const float
   } else if (dtype == NBEST_BF16 && H % 256 == 0 && H <= 1024) {
     const int grid = grid0 < 1024 ? grid0 : 1024;   // 512 ... 4096 blocks tie at 17 us for 100 MB (5.9 TB/s); 8192: 19.5
     switch (H / 256) {
-      case 1: ln_fwd_fast_kernel<1><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8); break;
-      case 2: ln_fwd_fast_kernel<2><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8); break;
-      case 3: ln_fwd_fast_kernel<3><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8); break;
-      default: ln_fwd_fast_kernel<4><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8); break;
+      case 1: ln_fwd_fast_kernel<1><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8, a_prev, a_new); break;
+      case 2: ln_fwd_fast_kernel<2><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8, a_prev, a_new); break;
+      case 3: ln_fwd_fast_kernel<3><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8, a_prev, a_new); break;
+      default: ln_fwd_fast_kernel<4><<<grid, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, eps, (uint8_t*)y8, a_prev, a_new); break;
     }
   } else if (dtype == NBEST_BF16) {
     DISPATCH_VPL(H, (ln_fwd_kernel<bf16, VPL><<<grid0, 256, 0, st>>>((const bf16*)x, gamma, beta, (bf16*)y, stats, M, H, eps)));
@@ -1022,7 +1032,7 @@ int nbest_internal_layernorm_fwd8(const void* x, const float* gamma, const float
 
 extern "C" int nbest_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                    int64_t M, int H, float eps, int dtype, nbest_stream_t stream) {
-  return nbest_internal_layernorm_fwd8(x, gamma, beta, y, nullptr, stats, M, H, eps, dtype, stream);
+  return nbest_internal_layernorm_fwd8(x, gamma, beta, y, nullptr, stats, M, H, eps, dtype, stream, nullptr, nullptr);
 }
 
 // f8 (bf16 fast path only): e4m3 copy + amax of the gradient the dense-layer GEMMs read (dx_drop under dropout, else dx)

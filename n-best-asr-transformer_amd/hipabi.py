@@ -19,7 +19,7 @@ EXPORTS = [
     "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes", "nbest_rows_gather", "nbest_rows_zero", "nbest_rows_add",
     "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_wgrad_pair_ws_bytes", "nbest_wgrad_pair", "nbest_pack_bn", "nbest_pack_weights", "nbest_pack_bn_fp8", "nbest_pack_weights_fp8", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
-    "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
+    "nbest_stc_heads_vjp", "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_wgrad_launches_per_layer", "nbest_encoder_forward",
     "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_wgrad_fp8", "nbest_wgrad_fp8_ws_bytes", "nbest_wgrad_fp8_pair", "nbest_wgrad_fp8_pair_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
 ]
@@ -76,7 +76,7 @@ class EncoderDesc(C.Structure):
                 ("w8", C.c_void_p), ("w8_inv_scale", C.c_void_p), ("w8t", C.c_void_p), ("gamax_prev", C.c_void_p),
                 ("gamax_new", C.c_void_p), ("fp8_bwd", C.c_int32), ("pad2", C.c_int32),
                 ("wpk", C.c_void_p), ("wpkt", C.c_void_p), ("w8p", C.c_void_p), ("w8tp", C.c_void_p),
-                ("word_perm", C.c_void_p)]
+                ("word_perm", C.c_void_p), ("aamax_prev", C.c_void_p), ("aamax_new", C.c_void_p), ("fp8_act", C.c_int32), ("pad4", C.c_int32)]
 
 
 _lib = None
@@ -123,6 +123,7 @@ def lib():
         L.nbest_layernorm_bwd.argtypes = [vp] * 9 + [i64, i32, i32, i32, f32, u64, u32, vp, sz, vp]
         L.nbest_colsum.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, sz, vp]
         L.nbest_stc_heads.argtypes = [vp, i64, vp, vp, C.POINTER(LabelSpaceC)] + [vp] * 8 + [i32] * 5 + [f32, u64, u32, vp, sz, vp]
+        L.nbest_stc_heads_vjp.argtypes = [vp, C.POINTER(LabelSpaceC)] + [vp] * 8 + [i32, i32, i32, f32, u64, u32, vp, sz, vp]
         L.nbest_cls_mse.argtypes = [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp]
         L.nbest_cls_grad_scatter.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.nbest_stc_decode.argtypes = [vp, vp, C.POINTER(LabelSpaceC), vp, vp, i32, vp]
@@ -141,10 +142,10 @@ def lib():
         L.nbest_cast_bf16_to_fp8.argtypes = [vp, vp, i64, vp]
         L.nbest_wgrad_fp8_ws_bytes.restype = C.c_size_t
         L.nbest_wgrad_fp8_ws_bytes.argtypes = [i64, i64, i64]
-        L.nbest_wgrad_fp8.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, i32, vp, sz, vp]
+        L.nbest_wgrad_fp8.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i32, vp, sz, vp]
         L.nbest_wgrad_fp8_pair_ws_bytes.restype = C.c_size_t
         L.nbest_wgrad_fp8_pair_ws_bytes.argtypes = [i64, i64, i64, i64]
-        L.nbest_wgrad_fp8_pair.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, i64, i64, i64, i64, vp, i64, i64, i32, vp, sz, vp]
+        L.nbest_wgrad_fp8_pair.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, i64, i64, i32, vp, sz, vp]
         L.nbest_quantize_weights_fp8.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
         L.nbest_gemm_fp8_ws_bytes.restype = C.c_size_t
         L.nbest_gemm_fp8_ws_bytes.argtypes = [C.POINTER(GemmFp8Args)]
@@ -345,25 +346,26 @@ def gemm_fp8(A8, W8, M, N, K, bias, out_scale=1.0, epilogue=EPI_BIAS, R=None, dr
     return (out, U, C8) if epilogue == EPI_BIAS_GELU else out
 
 
-def wgrad_fp8(dY8, X8, M, N, K, a_amax=None, out=None, accumulate=False):
-    """dW[M,N] (fp32) = dY8^T . X8 over K token rows, both operands token-major e4m3 bytes"""
+def wgrad_fp8(dY8, X8, M, N, K, a_amax=None, out=None, accumulate=False, x_amax=None):
+    """dW[M,N] (fp32) = dY8^T . X8 over K token rows, both operands token-major e4m3 bytes; a_amax / x_amax: the amax words the
+    delayed scales of dY8 / X8 were derived from (None = unit scale)"""
     if out is None:
         out = torch.zeros(M, N, dtype=torch.float32, device=dY8.device)
     ws = _ws(lib().nbest_wgrad_fp8_ws_bytes(M, N, K), dY8.device)
-    check(lib().nbest_wgrad_fp8(ptr(dY8), ptr(X8), ptr(out), M, N, K, dY8.stride(0), X8.stride(0), out.stride(0), ptr(a_amax),
+    check(lib().nbest_wgrad_fp8(ptr(dY8), ptr(X8), ptr(out), M, N, K, dY8.stride(0), X8.stride(0), out.stride(0), ptr(a_amax), ptr(x_amax),
                                 int(accumulate), ptr(ws), ws.numel(), stream_ptr()), "wgrad_fp8")
     return out
 
 
-def wgrad_fp8_pair(dY8a, X8a, dY8b, X8b, amax_a=None, amax_b=None, outs=None, accumulate=False):
+def wgrad_fp8_pair(dY8a, X8a, dY8b, X8b, amax_a=None, amax_b=None, outs=None, accumulate=False, xamax_a=None, xamax_b=None):
     """(dY8a^T . X8a / s_a, dY8b^T . X8b / s_b) in fp32 by ONE launch; dY8_i [K, M_i], X8_i [K, N] token-major e4m3 bytes"""
     K, N = X8a.shape
     Ma, Mb = dY8a.shape[1], dY8b.shape[1]
     oa, ob = outs if outs is not None else (torch.zeros(Ma, N, dtype=torch.float32, device=X8a.device),
                                             torch.zeros(Mb, N, dtype=torch.float32, device=X8a.device))
     ws = _ws(lib().nbest_wgrad_fp8_pair_ws_bytes(Ma, Mb, N, K), X8a.device)
-    check(lib().nbest_wgrad_fp8_pair(ptr(dY8a), ptr(X8a), ptr(oa), Ma, dY8a.stride(0), X8a.stride(0), oa.stride(0), ptr(amax_a),
-                                     ptr(dY8b), ptr(X8b), ptr(ob), Mb, dY8b.stride(0), X8b.stride(0), ob.stride(0), ptr(amax_b),
+    check(lib().nbest_wgrad_fp8_pair(ptr(dY8a), ptr(X8a), ptr(oa), Ma, dY8a.stride(0), X8a.stride(0), oa.stride(0), ptr(amax_a), ptr(xamax_a),
+                                     ptr(dY8b), ptr(X8b), ptr(ob), Mb, dY8b.stride(0), X8b.stride(0), ob.stride(0), ptr(amax_b), ptr(xamax_b),
                                      N, K, int(accumulate), ptr(ws), ws.numel(), stream_ptr()), "wgrad_fp8_pair")
     return oa, ob
 
@@ -504,8 +506,23 @@ class DeviceLabelSpace:
                              self.head_row.data_ptr())
 
 
+def heads_ws(B, R, H, device):
+    """a PRIVATE workspace for stc_heads (the default is a shared scratch buffer): the autograd bridge keeps it until stc_heads_vjp"""
+    return torch.empty(lib().nbest_heads_ws_bytes(B, R, H), dtype=torch.uint8, device=device)
+
+
+def stc_heads_vjp(Wh, dls, top, bott, dtop, dbott, dfin, B, H, dWh, dbh, ws, accumulate=True, drop_p=0.0, seed=0, drop_stream=0):
+    """d(CLS) [B, H] (and dWh / dbh, accumulated) for arbitrary upstream gradients of top / bottoms / final; ``ws``: the workspace of
+    the stc_heads call that produced top / bott"""
+    dcls = torch.empty(B, H, dtype=torch.float32, device=Wh.device)
+    check(lib().nbest_stc_heads_vjp(ptr(Wh), C.byref(dls.c), ptr(top), ptr(bott), ptr(dtop), ptr(dbott), ptr(dfin), ptr(dcls), ptr(dWh),
+                                    ptr(dbh), B, H, int(accumulate), drop_p, seed, drop_stream, ptr(ws), ws.numel(), stream_ptr()),
+          "stc_heads_vjp")
+    return dcls
+
+
 def stc_heads(hidden, cls_stride, Wh, bh, dls, labels_f, B, H, need_grad=True, accumulate=False, drop_p=0.0, seed=0,
-              drop_stream=0, dWh=None, dbh=None):
+              drop_stream=0, dWh=None, dbh=None, ws=None):
     dev = Wh.device
     R, nt, nb = dls.n_rows, dls.labels.n_top, dls.labels.n_bottom
     f = dict(dtype=torch.float32, device=dev)
@@ -514,7 +531,8 @@ def stc_heads(hidden, cls_stride, Wh, bh, dls, labels_f, B, H, need_grad=True, a
     dcls = torch.empty(B, H, **f) if need_grad else None
     if need_grad and dWh is None:
         dWh, dbh = torch.zeros(R, H, **f), torch.zeros(R, **f)
-    ws = _ws(lib().nbest_heads_ws_bytes(B, R, H), dev)
+    if ws is None:
+        ws = _ws(lib().nbest_heads_ws_bytes(B, R, H), dev)
     check(lib().nbest_stc_heads(ptr(hidden), cls_stride, ptr(Wh), ptr(bh), C.byref(dls.c), ptr(labels_f), ptr(top), ptr(bott),
                                 ptr(fin), ptr(loss), ptr(dcls), ptr(dWh), ptr(dbh), B, H, dtype_code(hidden.dtype),
                                 int(need_grad), int(accumulate), drop_p, seed, drop_stream, ptr(ws), ws.numel(), stream_ptr()),
@@ -536,8 +554,8 @@ def cls_mse(hidden_a, stride_a, hidden_t, stride_t, B, H, da=None, dt=None, grad
     return loss
 
 
-def cls_grad_scatter(dcls, B, S, H, dtype):
-    dh = torch.empty(B * S, H, dtype=dtype, device=dcls.device)
+def cls_grad_scatter(dcls, B, S, H, dtype, out=None):
+    dh = out if out is not None else torch.empty(B * S, H, dtype=dtype, device=dcls.device)
     check(lib().nbest_cls_grad_scatter(ptr(dcls), ptr(dh), B, S, H, dtype_code(dtype), stream_ptr()), "cls_grad_scatter")
     return dh
 

@@ -185,16 +185,21 @@ def encode_utterance(seq, tokenizer, opt, n_best=None, max_seq_len=None):
 
 def collate(rows, pad_id, pin=False):
     """[(ids, seg | None)] -> right-padded int64 host tensors ``ids [B,S]``, ``seg [B,S] | None`` and the lengths
-    (bert_xlnet_inputs.py:87-102: pad id for ids, 0 for segments, width = batch maximum)"""
+    (bert_xlnet_inputs.py:87-102: pad id for ids, 0 for segments, width = batch maximum).  One masked numpy assignment per
+    tensor (round 3 copied row by row through torch.as_tensor: 18 ms per 256-utterance batch - with the real-data loop's
+    prefetch thread sharing the interpreter lock with the training loop, that was most of a step)."""
+    import numpy as np
     lens = [len(r[0]) for r in rows]
     width = max(lens)
-    ids = torch.full((len(rows), width), pad_id, dtype=torch.long, pin_memory=pin)
-    seg = torch.zeros((len(rows), width), dtype=torch.long, pin_memory=pin) if rows[0][1] is not None else None
-    for i, (r, sg) in enumerate(rows):
-        ids[i, :len(r)] = torch.as_tensor(r, dtype=torch.long)
-        if seg is not None:
-            seg[i, :len(sg)] = torch.as_tensor(sg, dtype=torch.long)
-    return ids, seg, lens
+    inside = np.arange(width)[None, :] < np.asarray(lens)[:, None]
+    ids = np.full((len(rows), width), pad_id, dtype=np.int64)
+    ids[inside] = np.concatenate([np.asarray(r[0], dtype=np.int64) for r in rows])
+    seg = None
+    if rows[0][1] is not None:
+        seg = np.zeros((len(rows), width), dtype=np.int64)
+        seg[inside] = np.concatenate([np.asarray(r[1], dtype=np.int64) for r in rows])
+    to_t = (lambda a: torch.from_numpy(a).pin_memory()) if pin else torch.from_numpy
+    return to_t(ids), (None if seg is None else to_t(seg)), lens
 
 
 def prepare_inputs_for_roberta(raw_in, tokenizer, opt, device, n_best=None, max_seq_len=None):

@@ -78,6 +78,67 @@ class _Pass:
         self.perm = None
 
 
+class _STCBridge(torch.autograd.Function):
+    """The reference's training seam VERBATIM (/root/reference/n_best_asr_bert.py:255-274): ``model(opt, ...)`` returns graph-attached
+    scores, the loop builds ANY loss from them (cal_total_loss there), calls ``total_loss.backward()`` and ``optimizer.step()``.
+    Forward = the HIP forward (both encoder passes + heads); backward = nbest_stc_heads_vjp for the upstream gradients autograd
+    hands over, then nbest_encoder_backward for the pass(es) that received a gradient.  Parameter gradients are ADDED into the
+    flat arena (``param.grad`` are views of it; call ``model.zero_grad()`` first, as the reference loop does).  The fused
+    ``forward_backward`` (losses + gradients analytically in the heads kernel) is what ``train_step`` uses; this bridge costs one
+    extra small launch and materialised score tensors, and exists so that a reference maintainer need not touch the loop."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, input_ids, trans_input_ids, seg_ids, trans_seg_ids, feats_from_transcript):
+        ctx.set_materialize_grads(False)
+        B, S = input_ids.shape
+        H = model.cfg.hidden_size
+        pa = model._pass(B, S, 0)
+        ha = model._encode(pa, input_ids, seg_ids, True)
+        pt = ht = None
+        St = 0
+        if trans_input_ids is not None:
+            St = trans_input_ids.shape[1]
+            pt = model._pass(B, St, 1)
+            ht = model._encode(pt, trans_input_ids, trans_seg_ids, True)
+        feats, Sf = (ht, St) if (feats_from_transcript and ht is not None) else (ha, S)
+        ws = hb.heads_ws(B, model.dls.n_rows, H, model.device)
+        seed = model._step_seed()
+        Wh, bh = model.arena.heads_wb()
+        labels_f = torch.zeros(B, model.labels.n_bottom, dtype=torch.float32, device=model.device)
+        top, bott, fin, _, _, _, _ = hb.stc_heads(feats, Sf * H, Wh, bh, model.dls, labels_f, B, H, need_grad=False, drop_p=model.dropout,
+                                                  seed=seed, drop_stream=900, ws=ws)
+        ctx.model, ctx.pa, ctx.pt, ctx.ws, ctx.seed = model, pa, pt, ws, seed
+        ctx.from_t = bool(feats_from_transcript and ht is not None)
+        ctx.save_for_backward(top, bott)
+        asr_cls = ha.view(B, S, H)[:, 0, :].float()
+        trans_cls = ht.view(B, St, H)[:, 0, :].float() if ht is not None else torch.zeros(0, device=model.device)
+        return top, bott, fin, asr_cls, trans_cls
+
+    @staticmethod
+    def backward(ctx, dtop, dbott, dfin, dasr, dtrans):
+        m = ctx.model
+        top, bott = ctx.saved_tensors
+        B, H = top.shape[0], m.cfg.hidden_size
+        z = lambda g, like: torch.zeros_like(like) if g is None else g.contiguous().float()
+        fin_like = torch.empty(B, m.labels.n_bottom, dtype=torch.float32, device=m.device)
+        dWh, dbh = m.arena.heads_grad_wb()
+        dcls = hb.stc_heads_vjp(m.arena.heads_wb()[0], m.dls, top, bott, z(dtop, top), z(dbott, bott), z(dfin, fin_like), B, H, dWh, dbh, ctx.ws,
+                                accumulate=True, drop_p=m.dropout, seed=ctx.seed, drop_stream=900)
+        d_asr = dasr.contiguous().float() if dasr is not None else None
+        d_tr = dtrans.contiguous().float() if (dtrans is not None and ctx.pt is not None) else None
+        if ctx.from_t:
+            d_tr = dcls if d_tr is None else d_tr + dcls
+        else:
+            d_asr = dcls if d_asr is None else d_asr + dcls
+        if d_tr is not None and ctx.pt is not None:
+            m._backward_pass(ctx.pt, d_tr, accumulate=True)
+        if d_asr is not None:
+            m._backward_pass(ctx.pa, d_asr, accumulate=True)
+        m._end_of_step_fp8(True)
+        m.step_counter += 1
+        return (None,) * 7
+
+
 class NBestSTCModel(nn.Module):
     def __init__(self, cfg: EncoderConfig, labels: LabelSpace, device="cuda", compute_dtype=torch.bfloat16, dropout=0.0,
                  seed=999, fp8_forward=False, fp8_backward=None):
@@ -96,6 +157,12 @@ class NBestSTCModel(nn.Module):
         self.fp8_backward = self.fp8_forward if fp8_backward is None else bool(fp8_backward)
         self._gamax_gen = 0                # which of arena.gamax[0/1] holds the previous pass's amax
         self._gamax_valid = False
+        # ... and the forward's four GEMM inputs per layer (x, ctx, x1, gelu(u)) are e4m3 copies with a DELAYED per-tensor scale
+        # 2^floor(log2(224 / amax of the same tensor in the previous step)); the first step after (re)loading weights is a
+        # calibration step: bf16 GEMMs, amax recorded (round 3 cast activations at unit scale and saturated silently beyond 448)
+        self._aamax_gen = 0
+        self._aamax_valid = False
+        self._step_fp8_fwd = False         # did the forward of the running step run in fp8 (its backward may then, too)
         if self.fp8_forward:
             if compute_dtype != torch.bfloat16:
                 raise RuntimeError("nbest_amd: fp8_forward rides on the bf16 path")
@@ -117,6 +184,8 @@ class NBestSTCModel(nn.Module):
         self._stash = {}                   # slot -> ONE grow-only activation stash, sized for the largest B*S seen
         self._ws = None
         self._ws_bytes = 0
+        self._dh = None                    # grow-only scratch of the backward's input gradient
+        self._anchor = None                # autograd bridge: a leaf that makes the outputs of forward() require grad
 
     # ---- plumbing ------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -128,6 +197,10 @@ class NBestSTCModel(nn.Module):
         if self.fp8_backward and self._gamax_valid:
             self._gamax_valid = False
             for t in self.arena.gamax:
+                t.zero_()
+        if self.fp8_forward and self._aamax_valid:
+            self._aamax_valid = False
+            for t in self.arena.aamax:
                 t.zero_()
 
     def load_reference_state(self, sd, strict=True):
@@ -226,6 +299,7 @@ class NBestSTCModel(nn.Module):
         d.seed = self._step_seed()
         if self.fp8_forward:
             d.w8, d.w8_inv_scale = self.arena.w8.data_ptr(), self.arena.w8_inv_scale.data_ptr()
+            self._set_fp8_forward(d)
         self._set_packed(d)
         self._set_fp8_backward(d)    # the forward leaves out the bf16 tensors an fp8 backward will not read
         out = C.c_void_p()
@@ -251,22 +325,49 @@ class NBestSTCModel(nn.Module):
         d.w8p = a.w8p.data_ptr() if ok8 else None
         d.w8tp = a.w8tp.data_ptr() if ok8 else None
 
+    def _set_fp8_forward(self, d):
+        """activation amax history of the fp8 forward: the same two generations for every pass of a step (ASR + transcript pass
+        record into the same words: the next step's scale covers both)"""
+        a = self.arena
+        d.aamax_prev, d.aamax_new = a.aamax[self._aamax_gen].data_ptr(), a.aamax[1 - self._aamax_gen].data_ptr()
+        d.fp8_act = int(self._aamax_valid)
+        self._step_fp8_fwd = self._aamax_valid
+
+    def _end_of_step_fp8(self, ran_backward):
+        """this step's amax words become the history of the next one (after the backward: it reads the forward's scaled copies)"""
+        if self.fp8_forward:
+            self._aamax_gen = 1 - self._aamax_gen
+            self.arena.aamax[1 - self._aamax_gen].zero_()
+            self._aamax_valid = True
+        if ran_backward and self.fp8_backward:
+            self._gamax_gen = 1 - self._gamax_gen
+            self.arena.gamax[1 - self._gamax_gen].zero_()
+            self._gamax_valid = True
+
     def _set_fp8_backward(self, d):
         """descriptor fields of the fp8 backward; the same values in the forward and the backward of one step"""
         if self.fp8_backward:
             a = self.arena
             d.w8t = a.w8t.data_ptr()
             d.gamax_prev, d.gamax_new = a.gamax[self._gamax_gen].data_ptr(), a.gamax[1 - self._gamax_gen].data_ptr()
-            d.fp8_bwd = int(self._gamax_valid)
-            a.lazy_w16t = self._gamax_valid       # steady state: every dgrad reads w8t, nobody reads the bf16 transposed copy
+            on = self._gamax_valid and self._aamax_valid      # the fp8 weight gradients read the fp8 forward's activation copies
+            d.fp8_bwd = int(on)
+            a.lazy_w16t = on                      # steady state: every dgrad reads w8t, nobody reads the bf16 transposed copy
 
     def _backward_pass(self, ps, dcls, accumulate, chunks=None, on_chunk_done=None):
         cfg = self.cfg
         self._set_fp8_backward(ps.desc)
-        if self.arena.w16t_stale and not (self.fp8_backward and self._gamax_valid):
+        if self.arena.w16t_stale and not (self.fp8_backward and self._gamax_valid and self._aamax_valid):
             self.arena.refresh_w16t()             # a bf16 backward after fp8 steps (history dropped, mode switched)
         self._set_packed(ps.desc)
-        dh = hb.cls_grad_scatter(dcls, ps.B, ps.S, cfg.hidden_size, self.compute_dtype)
+        # gradient w.r.t. the final hidden states [B*S, H] (zero except the CLS rows): ONE grow-only buffer, like the activation stash -
+        # real batches change shape every step, and a fresh 40-50 MB tensor of a new size per step sends the caching allocator to
+        # hipMalloc / hipFree (a device synchronisation) over and over
+        n_dh = ps.B * ps.S * cfg.hidden_size
+        if self._dh is None or self._dh.numel() < n_dh:
+            self._dh = None
+            self._dh = torch.empty(n_dh, dtype=self.compute_dtype, device=self.device)
+        dh = hb.cls_grad_scatter(dcls, ps.B, ps.S, cfg.hidden_size, self.compute_dtype, out=self._dh[:n_dh].view(ps.B * ps.S, cfg.hidden_size))
         ids, seg, pos, mask = ps.inputs
         if ps.perm is None:
             ps.perm = hb.word_perm(ids)
@@ -300,10 +401,22 @@ class NBestSTCModel(nn.Module):
             col += n
         return out
 
-    # ---- reference-compatible inference forward (models/model.py:35-73) -------------------------
-    @torch.no_grad()
+    # ---- reference-compatible forward (models/model.py:35-73) -----------------------------------
     def forward(self, opt, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, return_attns=False,
                 classifier_input_type="asr"):
+        """Training mode under autograd: graph-attached outputs (``_STCBridge``), so the reference's
+        ``total_loss.backward(); optimizer.step()`` loop body runs unmodified.  Otherwise (eval / no_grad): plain tensors."""
+        if self.training and torch.is_grad_enabled():
+            if self._anchor is None:
+                self._anchor = torch.zeros(1, device=self.device, requires_grad=True)    # what makes the outputs require grad
+            top, bott, fin, asr_cls, trans_cls = _STCBridge.apply(self._anchor, self, input_ids.contiguous(),
+                                                                  None if trans_input_ids is None else trans_input_ids.contiguous(), seg_ids,
+                                                                  trans_seg_ids, classifier_input_type == "transcript")
+            return top, self._bottoms_dict(bott), fin, asr_cls, (trans_cls if trans_input_ids is not None else None)
+        with torch.no_grad():
+            return self._forward_plain(input_ids, trans_input_ids, seg_ids, trans_seg_ids, classifier_input_type)
+
+    def _forward_plain(self, input_ids, trans_input_ids, seg_ids, trans_seg_ids, classifier_input_type):
         train = self.training
         B, S = input_ids.shape
         pa = self._pass(B, S, 0)
@@ -317,6 +430,7 @@ class NBestSTCModel(nn.Module):
             trans_cls = ht.view(B, St, -1)[:, 0, :].float()
         feats, Sf = (ht, St) if classifier_input_type == "transcript" else (ha, S)
         top, bott, fin, _, _, _, _ = self._heads(feats, Sf, None, need_grad=False, train=train)
+        self._end_of_step_fp8(False)
         return top, self._bottoms_dict(bott), fin, asr_cls, trans_cls
 
     # ---- one training forward + backward (n_best_asr_bert.py:249-264) ---------------------------
@@ -359,10 +473,7 @@ class NBestSTCModel(nn.Module):
                 self._backward_pass(pa, dcls, accumulate=True, chunks=chunks, on_chunk_done=on_chunk_done)
             else:
                 self._backward_pass(pa, dcls, accumulate=accumulate, chunks=chunks, on_chunk_done=on_chunk_done)
-        if need_grad and self.fp8_backward:     # this pass's amax becomes the history of the next one
-            self._gamax_gen = 1 - self._gamax_gen
-            self.arena.gamax[1 - self._gamax_gen].zero_()
-            self._gamax_valid = True
+        self._end_of_step_fp8(need_grad)
         self.step_counter += 1
         return dict(top=top, bott=bott, final=fin, loss_parts=loss, asr_cls=ha.view(B, S, H)[:, 0, :],
                     trans_cls=None if ht is None else ht.view(B, St, H)[:, 0, :])

@@ -335,8 +335,8 @@ def filter_informative(labels, ontology):
     return keep
 
 
-def _host_metrics(model, out, raw_labels, idx2label, counts, ontology=None):
-    pred = model.decode(out["top"], out["bott"]).cpu().tolist()
+def _count_metrics(pred, raw_labels, idx2label, counts, ontology=None):
+    """pred_one_sample + update_f1 + exact-match bookkeeping (n_best_asr_bert.py:198-215,283-288) from decoded index rows"""
     TP, FP, FN, corr, tot = counts
     all_preds = []
     for row, gold in zip(pred, raw_labels):
@@ -348,6 +348,57 @@ def _host_metrics(model, out, raw_labels, idx2label, counts, ontology=None):
         corr += int(set(pc) == set(gold))
         all_preds.append(pc)
     return (TP, FP, FN, corr, tot), all_preds
+
+
+def _host_metrics(model, out, raw_labels, idx2label, counts, ontology=None):
+    """synchronous form (drains the compute stream): kept for callers outside the epoch loops"""
+    return _count_metrics(model.decode(out["top"], out["bott"]).cpu().tolist(), raw_labels, idx2label, counts, ontology)
+
+
+class MetricsPipe:
+    """The per-sample decode of the reference (n_best_asr_bert.py:283-288) WITHOUT a host synchronisation per step: round 3 did
+    ``model.decode(...).cpu().tolist()`` after every step, which drains the compute stream - the GPU then idles while Python
+    prepares the next step.  Here the device decode of step i is enqueued on the compute stream, its int32 [B, 30] result travels
+    to pinned host memory on a side stream behind an event, and the host turns it into labels / F1 counts one step LATER (while
+    step i + 1 runs); ``finish()`` drains the last one.  Same counts, same order."""
+
+    def __init__(self, model, idx2label, ontology=None):
+        self.model, self.idx2label, self.ontology = model, idx2label, ontology
+        self.counts, self.preds = (0, 0, 0, 0, 0), []
+        self.cuda = model.device.type == "cuda"
+        self.side = torch.cuda.Stream(model.device) if self.cuda else None
+        self.pending = None
+
+    def push(self, out, raw_labels, tag=None):
+        pred = self.model.decode(out["top"], out["bott"])
+        if not self.cuda:
+            self._consume((pred, None, raw_labels, tag))
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.model.device))
+        host = torch.empty(pred.shape, dtype=pred.dtype).pin_memory()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            host.copy_(pred, non_blocking=True)
+            pred.record_stream(self.side)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        prev, self.pending = self.pending, (host, done, raw_labels, tag)
+        if prev is not None:
+            self._consume(prev)
+
+    def _consume(self, item):
+        host, done, raw_labels, tag = item
+        if done is not None:
+            done.synchronize()                 # the side stream's copy only: the compute stream keeps running the next step
+        self.counts, preds = _count_metrics(host.cpu().tolist(), raw_labels, self.idx2label, self.counts, self.ontology)
+        self.preds.append((tag, preds))
+
+    def finish(self):
+        if self.pending is not None:
+            self._consume(self.pending)
+            self.pending = None
+        return self.counts, self.preds
 
 
 class EncodedSplit:
@@ -363,8 +414,9 @@ class EncodedSplit:
         self.asr, self.trans, self.labels = data
         tok = opt.tokenizer
         nb, msl = getattr(opt, "n_best", None), getattr(opt, "max_seq_len", None)
-        self.rows = [encode_utterance(s, tok, opt, nb, msl) for s in self.asr]
-        self.trows = [encode_utterance(s, tok, opt, None, msl) for s in self.trans]
+        as_np = lambda r: (np.asarray(r[0], dtype=np.int64), None if r[1] is None else np.asarray(r[1], dtype=np.int64))
+        self.rows = [as_np(encode_utterance(s, tok, opt, nb, msl)) for s in self.asr]
+        self.trows = [as_np(encode_utterance(s, tok, opt, None, msl)) for s in self.trans]
         l2i = memory["label2idx"]
         self.y = torch.zeros(len(self.labels), len(l2i))
         for i, ls in enumerate(self.labels):
@@ -383,7 +435,7 @@ class EncodedSplit:
         tids, tseg, _ = collate([self.trows[j] for j in idx], self.pad, pin)
         y = self.y[torch.as_tensor(idx, dtype=torch.long)]
         # rows of the word-embedding table this batch touches (sparse gradient exchange under data parallelism)
-        rows = torch.unique(torch.cat([ids.reshape(-1), tids.reshape(-1)]))
+        rows = torch.from_numpy(np.unique(np.concatenate([ids.numpy().ravel(), tids.numpy().ravel()])))
         # tokens sorted by word id, ties in token order: what the deterministic embedding backward reduces over (nbest_embed_ln_bwd)
         perm, tperm = token_perm(ids), token_perm(tids)
         p_ = (lambda t: t.pin_memory()) if pin else (lambda t: t)
@@ -480,7 +532,8 @@ def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
     rank, world = dist_info()
     reducer = (GradReducer(model.arena, owner_ranges=getattr(opt.optimizer, "owner_ranges", None))
                if (dist.is_available() and dist.is_initialized()) else None)
-    counts, losses = (0, 0, 0, 0, 0), []
+    losses = []
+    pipe = MetricsPipe(model, memory["idx2label"])
     split = encoded(data, opt, memory)
     n_accum = max(1, int(getattr(opt, "n_accum_steps", 1) or 1))
     lists = batch_indices(len(split), max(1, int(opt.batchSize / n_accum)), shuffle=shuffle, seed=getattr(opt, "random_seed", 999) + epoch)
@@ -514,7 +567,8 @@ def train_epoch(model, data, opt, memory, epoch=0, shuffle=True):
                     reducer.reduce_all()
                 opt.optimizer.step()
         losses.append((out["loss_parts"], len(mine), len(lists[bi])))
-        counts, _ = _host_metrics(model, out, [split.labels[j] for j in mine], memory["idx2label"], counts)
+        pipe.push(out, [split.labels[j] for j in mine])
+    counts, _ = pipe.finish()
     return _finish(losses, counts, model.device, len(lists))
 
 
@@ -538,7 +592,8 @@ def eval_epoch(model, data, opt, memory, fp=None, efp=None):
     model.eval()
     rank, world = dist_info()
     onto = getattr(opt, "ontology", None)
-    counts, losses, chunks = (0, 0, 0, 0, 0), [], []
+    losses, chunks = [], []
+    pipe = MetricsPipe(model, memory["idx2label"], onto)
     split = encoded(data, opt, memory)
     # the reference builds its valid / test loaders with int(batchSize / n_accum_steps) too (n_best_asr_bert.py:529-531), and the
     # record is the mean over batches of sum / batch size: the partition (and the weight of a short last batch) must be the same
@@ -550,8 +605,10 @@ def eval_epoch(model, data, opt, memory, fp=None, efp=None):
         seg = b["seg"] if opt.add_segment_ids else None
         out = model.forward_backward(b["ids"], b["labels"], seg_ids=seg, need_grad=False)     # no MSE in eval (:331)
         losses.append((out["loss_parts"], len(mine), len(lists[bi])))
+        pipe.push(out, [split.labels[j] for j in mine], tag=(bi, mine))
+    counts, tagged = pipe.finish()
+    for (bi, mine), preds in tagged:
         raw_labels = [split.labels[j] for j in mine]
-        counts, preds = _host_metrics(model, out, raw_labels, memory["idx2label"], counts, onto)
         golds = [filter_informative(g, onto) if onto is not None else g for g in raw_labels]
         chunks.append((bi, rank, list(zip([split.asr[j] for j in mine], preds, golds))))
     cases = merge_cases(chunks)

@@ -108,9 +108,22 @@ def _fp8_scale(t, target=224.0):
     return 2.0 ** torch.floor(torch.log2(target / a)) if a > 0 else torch.tensor(1.0)
 
 
+_ACT_SCALE = [True]     # False: unit-scale e4m3 activations (saturating at +-448) - the round-3 arithmetic, kept as a yardstick leg
+
+
+def _e4m3_act(x):
+    """e4m3 copy of a forward activation with its per-tensor power-of-two scale 2^floor(log2(224 / max|x|)) - 2 x headroom, as the
+    weights (common.h fp8_ascale_of; the HIP path takes the amax from the previous step - delayed scaling; the parity tests run the
+    same batch twice, so that is this tensor's own amax)"""
+    if not _ACT_SCALE[0]:
+        return _e4m3(x)
+    s = _fp8_scale(x, 224.0)
+    return _e4m3(x * s) / s
+
+
 class _Fp8Linear(torch.autograd.Function):
-    """"fp8w" GEMMs of one nn.Linear.  Forward: y = e4m3(x) . e4m3(W * s_w)^T / s_w + b (per-matrix scale s_w,
-    nbest_quantize_weights_fp8; unit-scale activations).  Backward without ``bwd8``: the bf16 path's (bf16 gradient x bf16 activation
+    """"fp8w" GEMMs of one nn.Linear.  Forward: y = e4m3(x * s_x) / s_x . e4m3(W * s_w)^T / s_w + b (per-matrix scale s_w,
+    nbest_quantize_weights_fp8; per-tensor activation scale s_x, see _e4m3_act).  Backward without ``bwd8``: the bf16 path's (bf16 gradient x bf16 activation
     -> fp32 weight gradient, bf16 dgrad on the bf16 weight copy).  With ``bwd8`` both are fp8: g8 = e4m3(g * s_g) / s_g feeds the
     dgrad g8 . e4m3(W * s_w) / s_w and the weight gradient g8^T . e4m3(x) (the forward's own e4m3 copy of the input), with
     the per-tensor gradient scale s_g (the HIP path takes it from the previous pass's amax of the same tensor; the parity test
@@ -120,9 +133,10 @@ class _Fp8Linear(torch.autograd.Function):
     def forward(ctx, x, w, b, bwd8, x_is_f32):
         s = _fp8_scale(w)
         w8 = _e4m3(w * s) / s
-        ctx.save_for_backward(_e4m3(x) if bwd8 else _r(x) if x_is_f32 else x, w8 if bwd8 else _r(w))
+        x8 = _e4m3_act(x)
+        ctx.save_for_backward(x8 if bwd8 else _r(x) if x_is_f32 else x, w8 if bwd8 else _r(w))
         ctx.bwd8, ctx.round_dx = bwd8, x_is_f32
-        return F.linear(_e4m3(x), w8) + b
+        return F.linear(x8, w8) + b
 
     @staticmethod
     def backward(ctx, g):
@@ -209,8 +223,10 @@ def encode(enc, ids, seg, fp8=False, fp8_bwd=False, q8=True):
     return x[:, 0, :]
 
 
-def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, fp8=False, fp8_bwd=False, q8=True):
-    """oracle.model.OracleModel.forward (classifier_input_type 'asr') on the bf16-storage encoder; heads in fp32"""
+def forward(model, input_ids, trans_input_ids=None, seg_ids=None, trans_seg_ids=None, fp8=False, fp8_bwd=False, q8=True, act_scale=True):
+    """oracle.model.OracleModel.forward (classifier_input_type 'asr') on the bf16-storage encoder; heads in fp32.
+    ``act_scale`` False (with fp8): unit-scale e4m3 activations, what the fp8 forward did before it had activation scales"""
+    _ACT_SCALE[0] = bool(act_scale)
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             assert m.p == 0.0 or not model.training

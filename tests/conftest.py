@@ -35,7 +35,7 @@ def case_inputs(meta, labels):
     cfg = mk(num_hidden_layers=meta["L"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     sd = synth.model_state(cfg, labels, seed=meta["seed"])
     if meta.get("outliers"):
-        synth.pretrained_like(sd, cfg, seed=meta["seed"])
+        synth.pretrained_like(sd, cfg, seed=meta["seed"], ln_gain=meta.get("ln_gain", 10.0), col_gain=meta.get("col_gain", 20.0))
     batch = synth.nbest_batch(cfg, labels, meta["B"], meta["S"], n_best=meta["n_best"], seed=meta["seed"],
                               ragged=True, trans_len=meta["St"])
     return cfg, sd, batch

@@ -60,36 +60,33 @@ CASES = ["bert_L2", "bert_L2_noseg", "xlmr_L2", "bert_L12",
          "bert_L12_S256",        # BASELINE configs[3]: --add_l2_loss, seq_len 256, n_best 10, S_t 64, 12 layers
          "xlmr_L12",             # BASELINE configs[2]: xlm-roberta-base, 12 layers, seq_len 128
          "xlmrL_L4_S256",        # BASELINE configs[4] architecture: xlm-roberta-large shape, 4 layers, seq_len 256
-         "bert_L4_outliers"]     # "pretrained-like" statistics: outlier feature dimensions (LayerNorm gains x 10, columns x 20)
+         "bert_L4_outliers",     # "pretrained-like" statistics: outlier feature dimensions (LayerNorm gains x 10, columns x 20)
+         "xlmrL_L24_S256",       # BASELINE configs[4] AS WRITTEN: xlm-roberta-large, 24 layers, H 1024, seq_len 256, n_best 10
+         "bert_L4_outliers_big"] # outlier gains x 30: GEMM inputs beyond e4m3's +-448 (the fp8 forward's activation scales at work)
 FLOOR_FACTOR = 1.5
 SMALL_FACTOR = 2.0      # tensors whose error statistic is a handful of correlated draws (see `dense` below): 2 x the worst of them.
                         # (Round 3 widened this to 2.5 after a red run; round 4 made the step bit-reproducible - the embedding backward
                         # no longer uses float atomics - and took it back: VERDICT r3 item 2 (iii).)
-# north_star: bf16 scores within 1e-2 of the reference.  Asserted wherever the committed floor of the storage format itself leaves
-# room for it (floor maximum <= 1e-2 / 1.5); the cases where bf16 STORAGE alone is closer than that to 1e-2 are listed here,
-# with the floor maximum of the worst of top / final / bottoms (tests/golden/case_*.npz, floor/):
+# north_star: bf16 scores within 1e-2 of the reference.  ASSERTED for every (case, quantity) on which bf16 STORAGE itself stays
+# under 1e-2 in all five committed draws of the storage leg (tests/golden/case_*.npz, floor/ = the maximum over the draws); where
+# even one draw of plain bf16 storage exceeds it, no bf16 implementation can promise it - those cases are listed here:
 BF16_1E2_EXCEPTIONS = {
-    "bert_L12": "12 layers: floor 0.7e-2 .. 1.1e-2",
-    "bert_L12_S256": "12 layers, S = 256: floor 0.9e-2",
-    "xlmr_L12": "12 layers: floor 0.8e-2",
-    "xlmrL_L4_S256": "H = 1024, S = 256: floor 0.8e-2",
-    "xlmrL_L24_S256": "24 layers, H = 1024: floor above 1e-2",
-    "bert_L4_outliers": "pretrained-like outlier statistics: floor 2e-2 .. 4e-2",
-    "bert_L4_outliers_big": "outlier statistics, activations beyond 448: floor above 1e-2",
+    "bert_L12": "12 layers: storage draws reach 1.1e-2 (top / final) and 1.3e-2 (bottoms)",
+    "bert_L12_S256": "12 layers, S = 256: 1.0e-2 (top), 1.5e-2 (bottoms)",
+    "xlmr_L12": "12 layers: 1.1e-2 (bottoms)",
+    "xlmrL_L24_S256": "24 layers, H = 1024: 1.35e-2 .. 1.4e-2",
+    "bert_L4_outliers": "pretrained-like outlier statistics: 5e-2 .. 6e-2",
+    "bert_L4_outliers_big": "outlier statistics, activations beyond 448: 7.5e-2",
 }
 
 
-_LOSS_NORM = {}
-
-
 def _loss_bound(pf, z):
-    """The loss is ONE scalar per case: its committed floor is a single draw (xlmr_L12: 2.5e-5, a lucky one, where the neighbouring
-    cases have 2e-4 .. 9e-4), so neither the case's own floor nor the pooled maximum (round 3: up to 45 x looser for the shallow
-    cases) is a bar.  What the draw scales with is the noise of the scores the loss is computed from: the bound is
-    1.5 x rms-floor(final scores of THIS case) x the largest ratio loss-floor / rms-floor(final) over all cases of the leg."""
-    if pf not in _LOSS_NORM:
-        _LOSS_NORM[pf] = max(float(zz[pf + "loss_total"][0]) / float(zz[pf + "final"][1]) for zz in (load_case(c)[1] for c in CASES))
-    return FLOOR_FACTOR * _LOSS_NORM[pf] * float(z[pf + "final"][1])
+    """The loss is ONE scalar per case: the error of a storage leg on it is a single draw (bert_L2, five draws of the same leg:
+    1.5e-4 .. 8.6e-4).  The golden therefore holds the loss error of 1 + 4 draws of the leg on THIS case (make_golden.py
+    run_leg(jitter=k): the same arithmetic on weights jittered by 2^-12, i.e. the same function with every rounding re-drawn;
+    ADVICE r3: "keep the per-case loss floor ... commit floors from several rounding seeds per case and bound against their
+    maximum"): the bar is FLOOR_FACTOR x the largest of them."""
+    return FLOOR_FACTOR * float(np.max(z[pf + "loss_draws"]))
 
 
 def _cmp_floor(name, got, ref, floor, factor=FLOOR_FACTOR, slack=0.0):
@@ -123,7 +120,8 @@ def test_step_matches_reference_outputs(name, dtype, labels):
     Scores (top / final / bottoms) are a few hundred linear functions of B <= 4 noisy CLS rows - a handful of correlated draws,
     like the head gradients below: their MAXIMUM error is held to SMALL_FACTOR (2) x the floor's maximum, their rms error to
     FLOOR_FACTOR (1.5) x its rms; bf16 scores are additionally ASSERTED under the north_star's absolute 1e-2 wherever the storage
-    floor allows (BF16_1E2_EXCEPTIONS lists the cases where it does not).  The loss scalar: _loss_bound."""
+    floor allows (BF16_1E2_EXCEPTIONS lists the cases where it does not).  The loss scalar: _loss_bound.
+    Every committed floor is the MAXIMUM over five draws of its leg (make_golden.py run_leg / with_draws)."""
     meta, z = load_case(name)
     m, b, out = _run(meta, labels, dtype)
     f32 = dtype == torch.float32
@@ -139,18 +137,27 @@ def test_step_matches_reference_outputs(name, dtype, labels):
             _log(tag + "%s: absolute score error %.3e (north_star bf16 bar 1e-2: %s; floor of this storage format %.3e)" % (
                 key, e, "met" if e <= 1e-2 else "NOT met", float(fl(key)[0])))
             if dtype == torch.bfloat16:
-                if float(fl(key)[0]) <= 1e-2 / FLOOR_FACTOR:
+                if float(fl(key)[0]) <= 1e-2:
                     assert e <= 1e-2, "%s%s: bf16 score error %.3e exceeds the north_star's 1e-2 (storage floor %.3e)" % (tag, key, e, float(fl(key)[0]))
                 else:
                     assert name in BF16_1E2_EXCEPTIONS, "%s%s: storage floor %.3e leaves no room for the 1e-2 bar and the case is not a listed exception" % (
                         tag, key, float(fl(key)[0]))
+    if dtype == "fp8w" and "floor8u/final" in z.files and name == "bert_L4_outliers_big":
+        # activations beyond +-448: the fp8 forward stays at the floor of the SCALED e4m3 arithmetic (the bars above and below) and
+        # well inside what unit-scale activations - saturating silently, round 3 - would have produced
+        for key, val in (("final", out["final"]), ("asr_cls", out["asr_cls"])):
+            e = (torch.as_tensor(val).float().cpu() - torch.from_numpy(z[key])).abs().max().item()
+            _log(tag + "%s: error %.3e; scaled-activation leg %.3e, unit-scale (saturating) leg %.3e" % (key, e, float(z["floor8/" + key][0]), float(z["floor8u/" + key][0])))
+            assert e <= 0.6 * float(z["floor8u/" + key][0]), (key, e, float(z["floor8u/" + key][0]))
     if f32:
-        _cmp(tag + "asr_cls", out["asr_cls"], z["asr_cls"], atol=2e-4 if meta["L"] <= 2 else 4e-4)        # CLS rows are O(4)
+        # CLS rows are O(4); O(100+) with outlier gains: the fp32 bar scales with them
+        cls_tol = (2e-4 if meta["L"] <= 2 else 4e-4) * (max(1.0, float(np.abs(z["asr_cls"]).max()) / 8.0) if name == "bert_L4_outliers_big" else 1.0)
+        _cmp(tag + "asr_cls", out["asr_cls"], z["asr_cls"], atol=cls_tol)
     else:
         _cmp_floor(tag + "asr_cls", out["asr_cls"], z["asr_cls"], fl("asr_cls"))
     if meta["add_l2"]:
         if f32:
-            _cmp(tag + "trans_cls", out["trans_cls"], z["trans_cls"], atol=2e-4 if meta["L"] <= 2 else 4e-4)
+            _cmp(tag + "trans_cls", out["trans_cls"], z["trans_cls"], atol=cls_tol)
         else:
             _cmp_floor(tag + "trans_cls", out["trans_cls"], z["trans_cls"], fl("trans_cls"))
     lp = out["loss_parts"].cpu()
@@ -190,6 +197,9 @@ def test_step_matches_reference_outputs(name, dtype, labels):
     # pure-noise quantity (mathematically zero), so: the worst layer of the bf16-storage oracle, not the same layer
     kb_floor = max(float(z[k[npf:]]) * (1.0 + float(z[k][0])) for k in z.files
                    if k.startswith(pf + "gnorm/") and k.endswith("attention.self.key.bias"))
+    # bert_L4_outliers_big: activations of O(1000) and a loss of 7 000 - two fp32 implementations of the step (oracle and reference,
+    # make_golden.py) already disagree 30 x more than on the plain cases there; the fp32 gradient bars scale the same way
+    f32_slack = max(1.0, float(z["act_amax"].max()) / 25.0) if (f32 and name == "bert_L4_outliers_big") else 1.0
     rows_ns, bad = [], []
     for key in z.files:
         if key.startswith("gnorm/"):
@@ -202,12 +212,16 @@ def test_step_matches_reference_outputs(name, dtype, labels):
                 # gradient of the same layer; bf16: against the noise the bf16-storage oracle leaves there
                 qn = named[name.replace(".key.", ".query.")].grad.norm().item()
                 # (outlier-statistics case: activations of O(100) instead of O(1) put proportionally more fp32 rounding noise there)
-                if got > (1e-5 * qn * (10.0 if meta.get("outliers") else 1.0) if f32 else FLOOR_FACTOR * kb_floor):
+                # (the variant with LayerNorm gains x 30: measured 2.9e-4 of the query-bias gradient - activations of O(1000))
+                kb_f32 = 1e-5 * (1.0 if not meta.get("outliers") else (10.0 if meta.get("ln_gain", 10.0) <= 10.0 else 100.0))
+                # (... or 20 x the noise the REFERENCE itself leaves there - its committed key-bias gradient norm: at 24 layers the
+                # query-bias gradient is small and the yardstick above with it)
+                if got > (max(kb_f32 * qn, 20.0 * ref) if f32 else FLOOR_FACTOR * kb_floor):
                     bad.append((key, got, kb_floor, qn))
                 continue
             rel = abs(got - ref) / max(ref, 1e-6)
             ns_floor = ns_floor_of[name] if dense(name) else sparse_ns
-            if rel > (2e-3 if f32 else (FLOOR_FACTOR if dense(name) else SMALL_FACTOR) * ns_floor) + (1e-7 if f32 else 1e-4) / max(ref, 1e-6):
+            if rel > (2e-3 * f32_slack if f32 else (FLOOR_FACTOR if dense(name) else SMALL_FACTOR) * ns_floor) + (1e-7 if f32 else 1e-4) / max(ref, 1e-6):
                 bad.append((key, got, ref, ns_floor))
             if "samp/" + name in z.files:
                 idx = torch.from_numpy(np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF).randint(0, g.numel(), size=512)).cuda()
@@ -218,7 +232,7 @@ def test_step_matches_reference_outputs(name, dtype, labels):
                     rows_ns.append((err / max(sim_err, 1e-30), err / max(sig, 1e-30), sim_err / max(sig, 1e-30), name))
                 else:
                     sim_err = sparse_samp * sig
-                lim = 2e-3 * sig + 1e-9 if f32 else (FLOOR_FACTOR if dense(name) else SMALL_FACTOR) * sim_err + 2.0 ** -9 * sig
+                lim = 2e-3 * f32_slack * sig + 1e-9 if f32 else (FLOOR_FACTOR if dense(name) else SMALL_FACTOR) * sim_err + 2.0 ** -9 * sig
                 if not f32 and (pf + "sampq/" + name) in z.files:
                     # outlier-statistics case: heavy-tailed gradient tensors - the rms of 512 samples hangs on the few giant elements
                     # it contains (whole-tensor noise-to-signal of HIP and oracle leg agree to 3 %, profiles/r03_floor_outliers.log),
@@ -234,7 +248,7 @@ def test_step_matches_reference_outputs(name, dtype, labels):
             got = g.reshape(-1, g.shape[-1])[:8, :64] if g.dim() > 1 else g[:64]
             # (fp8w: e4m3's coarse grid gives the maximum over a slice a heavier tail than bf16's - 3 x instead of 2 x; the rms-type
             # bars above stay at 1.5 x)
-            _cmp(tag + key[-52:], got, z[key], rtol=2e-3 if f32 else (3.0 if dtype == "fp8w" else 2.0) * gs_floor + 2.0 ** -8)
+            _cmp(tag + key[-52:], got, z[key], rtol=2e-3 * f32_slack if f32 else (3.0 if dtype == "fp8w" else 2.0) * gs_floor + 2.0 ** -8)
     rows_ns.sort(reverse=True)
     med = rows_ns[len(rows_ns) // 2]
     _log(tag + "gradient noise-to-signal on 512 sampled elements per dense tensor (%d tensors), HIP / storage leg of the oracle: median ratio "
@@ -243,7 +257,7 @@ def test_step_matches_reference_outputs(name, dtype, labels):
     assert not bad, bad[:4]
     rows = torch.from_numpy(z["wordgrad_rows"]).cuda()
     wg = named["bert_encoder.embeddings.word_embeddings.weight"].grad
-    _cmp(tag + "word-embedding grad rows", wg[rows, :64], z["wordgrad_vals"], rtol=2e-3 if f32 else (3.0 if dtype == "fp8w" else 2.0) * gs_floor + 2.0 ** -8)
+    _cmp(tag + "word-embedding grad rows", wg[rows, :64], z["wordgrad_vals"], rtol=2e-3 * f32_slack if f32 else (3.0 if dtype == "fp8w" else 2.0) * gs_floor + 2.0 ** -8)
 
 
 @pytest.mark.parametrize("name", ["bert_L2", "xlmr_L2"])
@@ -818,3 +832,69 @@ def test_fp8w_full_size_tracks_bf16(labels):
                 worst = (rel, cos, s_.name)
             assert rel <= 0.15 and cos >= 0.99, (s_.name, rel, cos)
     _log("full-size fp8w vs bf16: loss %.4f vs %.4f, worst tensor %s rel %.3f cos %.4f" % (l8, l16, worst[2][-50:], worst[0], worst[1]))
+
+
+@pytest.mark.parametrize("add_l2,dropout", [(True, 0.0), (False, 0.3)])
+def test_autograd_bridge_runs_the_reference_loop_body(add_l2, dropout, labels):
+    """VERDICT r3 "missing 4" / item 9: the reference's loop body VERBATIM (/root/reference/n_best_asr_bert.py:255-274) -
+    ``model(opt, ...)`` -> a loss built by the CALLER from the returned scores (here the oracle's restatement of cal_total_loss, on
+    the GPU) -> ``total_loss.backward()`` -> ``optimizer.step()``.  In training mode forward() returns graph-attached tensors
+    (model._STCBridge); backward() feeds the upstream gradients through nbest_stc_heads_vjp and nbest_encoder_backward.  The
+    gradients must equal the fused path's (forward_backward: the same loss differentiated analytically inside the heads kernel)
+    to fp32 rounding, with and without the CLS-MSE term (whose gradient reaches BOTH encoder passes), and with the heads' feature
+    dropout on (the vjp re-uses the forward's mask bits)."""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    from nbest_amd.optim import HipBertAdam
+    from oracle import stc
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = synth.model_state(cfg, labels, seed=33)
+    batch = synth.nbest_batch(cfg, labels, 5, 40, n_best=5, seed=9, ragged=True, trans_len=12)
+    b = {k: torch.from_numpy(v).cuda() for k, v in batch.items()}
+    b2t = stc.bottom2top_matrix(labels.top2bottom).cuda()
+
+    def build():
+        m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=torch.float32, dropout=dropout, seed=4)
+        m.load_reference_state(sd)
+        m.train()
+        return m, HipBertAdam(m, lr=5e-4, bert_lr=3e-5, warmup=0.1, t_total=40)
+
+    # fused path
+    mf, of = build()
+    out = mf.forward_backward(b["ids"], b["labels"], seg_ids=b["seg"], trans_input_ids=b["tids"], trans_seg_ids=b["tseg"], add_l2_loss=add_l2)
+    torch.cuda.synchronize()
+    g_fused = mf.arena.g.clone()
+    of.step()
+    # the reference's loop body on the bridge
+    mb, ob = build()
+    mb.zero_grad()
+    top, bottoms, final, asr_cls, trans_cls = mb(None, b["ids"], b["tids"], seg_ids=b["seg"], trans_seg_ids=b["tseg"], classifier_input_type="asr")
+    assert top.requires_grad and final.requires_grad and asr_cls.requires_grad and bottoms["lin_2"].requires_grad
+    rec, total, parts = stc.total_loss(top, bottoms, final, b["labels"], labels.top2bottom, b2t, asr_cls, trans_cls, add_l2)
+    total.backward()
+    torch.cuda.synchronize()
+    g_bridge = mb.arena.g.clone()
+    ob.step()
+    torch.cuda.synchronize()
+    assert abs(total.item() - out["loss_parts"].sum().item()) <= 2e-6 * abs(total.item())
+    assert torch.equal(out["top"], top.detach()) and torch.equal(out["final"], final.detach())
+    a = mf.arena
+    worst = (0.0, "")
+    for s_ in a.slots:
+        if "pooler" in s_.name or s_.name.endswith("attention.self.key.bias"):
+            continue
+        x, y = a.view(g_bridge, s_.name), a.view(g_fused, s_.name)
+        err = (x - y).abs().max().item() / max(y.abs().max().item(), 1e-20)
+        worst = max(worst, (err, s_.name))
+        assert err <= 2e-5, (s_.name, err)
+    _log("autograd bridge vs fused step (add_l2 %s, head dropout %.1f): worst relative gradient difference %.2e (%s)" % (add_l2, dropout, worst[0], worst[1]))
+    # one BertAdam step on either set of gradients: the same parameters.  (Mean, not max: BertAdam divides by sqrt(v) + 1e-6, so an
+    # element whose gradient is rounding noise moves by an order-dependent +-lr * 3.16 - in the reference too; tests/test_dp_gpu.py.)
+    dp = (mb.arena.p - mf.arena.p).abs()
+    _log("   ... parameters after one BertAdam step: mean |d| %.2e, max |d| %.2e" % (dp.mean().item(), dp.max().item()))
+    assert dp.mean().item() <= 1e-7
+    # eval mode / no_grad: plain tensors, as before
+    mb.eval()
+    t2 = mb(None, b["ids"], b["tids"], seg_ids=b["seg"], trans_seg_ids=b["tseg"])[0]
+    assert not t2.requires_grad

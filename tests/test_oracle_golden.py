@@ -71,12 +71,14 @@ def test_bf16_storage_leg_reproduces_committed_floor(labels):
     stop, sbot, sfin, sasr, str_ = bf16sim.forward(m, t["ids"], t["tids"], seg_ids=t["seg"], trans_seg_ids=t["tseg"])
     for key, a, b in (("top", stop, top), ("final", sfin, final), ("asr_cls", sasr, asr), ("trans_cls", str_, tr)):
         got = (a - b).abs().max().item()
-        assert 0.7 * float(z["floor/" + key][0]) <= got <= 1.3 * float(z["floor/" + key][0]), (key, got, float(z["floor/" + key][0]))
+        assert 0.7 * float(z["floor0/" + key][0]) <= got <= 1.3 * float(z["floor0/" + key][0]), (key, got, float(z["floor0/" + key][0]))
+        assert got <= 1.05 * float(z["floor/" + key][0])          # the committed floor is the maximum over five draws of this leg
     # and it is a bf16-sized perturbation, not a different function: far above fp32 noise, far below the signal
     assert 1e-4 < (stop - top).abs().max().item() < 2e-2
 
 
-ALL_CASES = ["bert_L2", "bert_L2_noseg", "xlmr_L2", "bert_L12", "bert_L12_S256", "xlmr_L12", "xlmrL_L4_S256", "bert_L4_outliers"]
+ALL_CASES = ["bert_L2", "bert_L2_noseg", "xlmr_L2", "bert_L12", "bert_L12_S256", "xlmr_L12", "xlmrL_L4_S256", "bert_L4_outliers",
+             "xlmrL_L24_S256", "bert_L4_outliers_big"]
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
@@ -87,13 +89,15 @@ def test_8bit_gelu_derivative_costs_no_gradient_accuracy(name):
     noise-to-signal of the 8-bit leg must not exceed the bf16 leg's by more than the draw-to-draw spread of the two legs
     (median over the matrices within 5 %, worst matrix within 20 %), and the score floors must agree."""
     meta, z = load_case(name)
-    dense = [k[len("floor/ns/"):] for k in z.files if k.startswith("floor/ns/bert_encoder.encoder.") and k.endswith(".weight")
+    # (floor0/ = the unjittered draw of the leg: floor/ itself is the maximum over five draws since round 4)
+    dense = [k[len("floor0/ns/"):] for k in z.files if k.startswith("floor0/ns/bert_encoder.encoder.") and k.endswith(".weight")
              and "LayerNorm" not in k]
     assert len(dense) >= 12
-    ratios = sorted(float(z["floor/ns/" + n][0]) / max(float(z["floorb/ns/" + n][0]), 1e-30) for n in dense)
+    ratios = sorted(float(z["floor0/ns/" + n][0]) / max(float(z["floorb/ns/" + n][0]), 1e-30) for n in dense)
     assert ratios[len(ratios) // 2] <= 1.05 and ratios[-1] <= 1.2, (ratios[len(ratios) // 2], ratios[-1])
     for k in ("top", "final", "bottoms"):
-        assert float(z["floor/" + k][0]) <= 1.25 * float(z["floorb/" + k][0]) + 1e-6, k
+        assert float(z["floor0/" + k][0]) <= 1.25 * float(z["floorb/" + k][0]) + 1e-6, k
+        assert float(z["floor/" + k][0]) >= float(z["floor0/" + k][0])
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
@@ -104,10 +108,21 @@ def test_fp8_floor_is_committed_for_every_case(name):
     meta, z = load_case(name)
     for k in ("top", "final", "bottoms", "asr_cls", "loss_total"):
         assert ("floor8/" + k) in z.files
-        assert float(z["floor8/" + k][0]) >= 0.8 * float(z["floor/" + k][0]), k
-    assert float(z["floor8/top"][0]) < 0.15
+        if k != "loss_total":        # (the loss is ONE scalar: its error in either leg is a single draw, see tests/test_model_gpu.py _loss_bound)
+            # (outlier models: the bf16 leg's storage noise on 100+-sized activations already dominates, so the two floors are
+            # draws of comparable noise - 0.7; elsewhere the fp8 floor sits above the bf16 one)
+            assert float(z["floor8/" + k][0]) >= (0.7 if meta.get("outliers") else 0.8) * float(z["floor/" + k][0]), k
+    assert float(z["floor8/top"][0]) < 0.15 * max(1.0, meta["L"] / 12.0) ** 0.5      # (storage noise grows like sqrt(depth): 24 layers 0.18)
+    if name == "bert_L4_outliers_big":
+        # the yardstick leg with UNIT-scale e4m3 activations (the fp8 forward before round 4).  Activations beyond 448 saturate in it:
+        # several times the error of the per-tensor scales - what the scale is worth.  (On bert_L4_outliers, amax 260, nothing
+        # saturates and the two legs are two draws of the same noise: a power-of-two scale leaves every normal e4m3 value unchanged.)
+        assert float(z["act_amax"].max()) > 448.0
+        assert float(z["floor8u/final"][0]) >= 2.5 * float(z["floor8/final"][0])
+        assert float(z["floor8u/asr_cls"][0]) >= 2.5 * float(z["floor8/asr_cls"][0])
     n8 = [k for k in z.files if k.startswith("floor8/ns/")]
     assert len(n8) == len([k for k in z.files if k.startswith("floor/ns/")]) > 20
+    assert len(z["floor/loss_draws"]) == len(z["floor8/loss_draws"]) == 5       # the loss bar: five draws of each leg
     assert any(k.startswith("floor8/samp/") for k in z.files) and "floor8/wordgrad" in z.files
 
 
