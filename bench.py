@@ -239,6 +239,8 @@ def main():
                     "through EncodedSplit + Prefetcher + train_epoch, decode and F1 included) as a second JSON key `real_data` (N = 1 only)")
     ap.add_argument("--epochs", type=int, default=2, help="--real: epochs over the tiled split (the last one is reported)")
     a = ap.parse_args()
+    from nbest_amd import trainer as _trainer
+    _trainer.limit_host_threads()            # the container's CPU quota, not the machine's core count (trainer.limit_host_threads)
 
     # NBEST_BENCH_REHEARSAL=1: the N ranks share cuda:0 and talk through gloo - the whole multi-rank code path (sharded optimizer,
     # reduce-to-owner buckets, sparse row exchange, tear-down, rank 0's extra measurements) on a ONE-GPU box; its timings mean nothing

@@ -178,7 +178,8 @@ typedef struct nbest_gemm_fp8_args {
    * bits) at a_amax - the DELAYED per-tensor scale its producer used: a gradient tensor (dgrad epilogues NONE, RES, DGELU:
    * T = 56, 8 x headroom) or, round 4, a forward activation (BIAS, BIAS_GELU, BIAS_DROP_RES: T = 224, 2 x headroom); the
    * accumulator is divided by s.  NULL = unit scale.
-   * DGELU: C = acc * gelu'(U) in bf16; optional C8 = e4m3(C * s_c), s_c from *c8_amax_prev; *c8_amax_new = max(|C|) (atomic);
+   * DGELU: C = acc * gelu'(U) in bf16; optional C8 = e4m3(C * s_c), s_c from *c8_amax_prev; max(|C|) recorded into the slot block c8_amax_new
+   * (NBEST_AMAX_TENSOR_WORDS words, see nbest_fp8_amax_fold);
    * optional colsum_out[N] (+)= column sums of C (the FFN-up bias gradient), needs ws >= nbest_gemm_fp8_ws_bytes().
    * BIAS_GELU: C8 = e4m3(gelu * s_c) with the same two fields (the activation scale of the FFN-down GEMM's input).          */
   const uint32_t* a_amax;
@@ -323,6 +324,11 @@ int nbest_cls_grad_scatter(const float* dcls, void* dhidden, int B, int S, int H
  * multi-value top the argmax of its head (first maximum), -1 when none_flag[that bottom] != 0.      */
 int nbest_stc_decode(const float* top, const float* bott, const nbest_label_space* ls,
                      const uint8_t* none_flag, int32_t* pred, int B, nbest_stream_t stream);
+/* `pred` may be any device-ACCESSIBLE memory - in particular mapped pinned host memory (hipHostMalloc): the rows then land on the
+ * host without a copy command.  nbest_stream_stamp writes `value` to *flag (device-accessible, system-scope release) in stream order:
+ * stamped after a decode into host memory it tells a polling host thread that the rows are complete - the per-step prediction
+ * hand-off of the reference's loop (n_best_asr_bert.py:283-288) without a hipMemcpy, an event or a stream synchronisation. */
+int nbest_stream_stamp(int32_t* flag, int32_t value, nbest_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9  multi-tensor BertAdam over flat arenas
@@ -365,6 +371,14 @@ typedef struct nbest_matrix_desc {
   int32_t rows, cols;
   int32_t tile_start, pad;
 } nbest_matrix_desc;
+/* Recording side of the delayed fp8 scales.  Every kernel that records a tensor's amax (gamax_new / aamax_new of the encoder
+ * descriptor, c8_amax_new of nbest_gemm_fp8_args) is handed a block of NBEST_AMAX_TENSOR_WORDS uint32 words for that tensor, not
+ * one word: it raises ONE of 16 words spaced 256 bytes apart (picked by its block index), because device-scope accesses to a
+ * single word serialise (about 1 ns each: the 65 536 waves of an e4m3 cast spent 100 us on them).  nbest_fp8_amax_fold writes
+ * out[t] = max over the 16 words of tensor t (the single word the NEXT pass reads as *_amax_prev / a_amax) and zeroes the slots.
+ * slots: uint32 [n_tensors][NBEST_AMAX_TENSOR_WORDS], zero-initialised by the caller once. */
+#define NBEST_AMAX_TENSOR_WORDS 1024
+int nbest_fp8_amax_fold(void* slots, void* out, int32_t n_tensors, nbest_stream_t stream);
 /* e4m3 copy of the weight matrices (same element offsets, ONE byte per element) from the fp32 master, one scale per
  * matrix: w8 = e4m3(w * 2^floor(log2(224 / max|w|))); inv_scale[i] = 1 / scale of matrix i (device, [n_matrices]).
  * w8t (optional): the same e4m3 values written transposed ([cols][rows] at the matrix' offset; n_tiles = 64x64 tiles over all
@@ -424,11 +438,12 @@ typedef struct nbest_encoder_desc {
    * are e4m3 copies written by the producers with a DELAYED per-tensor scale (aamax_* below); everything else is the bf16 path. */
   const void* w8;
   const float* w8_inv_scale;
-  /* optional fp8 dgrads (needs w8): transposed e4m3 weight copy and the per-(layer, tensor) gradient amax history, uint32
+  /* optional fp8 dgrads (needs w8): transposed e4m3 weight copy and the per-(layer, tensor) gradient amax history gamax_prev, uint32
    * float bits [4 L]: index 4 l + {0: FFN-down input gradient, 1: FFN-up input gradient (after GELU'), 2: attention-out
-   * input gradient, 3: dQ|dK|dV}.  The backward always RECORDS this pass's amax into gamax_new (when non-NULL); with
-   * fp8_bwd != 0 the producers also write e4m3 copies scaled from gamax_prev and the four dgrad GEMMs of a layer run on the
-   * fp8 MFMA.  The caller swaps prev/new between passes and sets fp8_bwd only once a history exists.                      */
+   * input gradient, 3: dQ|dK|dV}.  The backward always RECORDS this pass's amax (when gamax_new is non-NULL) into gamax_new, which is
+   * a SLOT ARRAY uint32 [4 L][NBEST_AMAX_TENSOR_WORDS] (see nbest_fp8_amax_fold); with fp8_bwd != 0 the producers also write e4m3
+   * copies scaled from gamax_prev and the four dgrad GEMMs of a layer run on the fp8 MFMA.  Between passes the caller folds the
+   * slots into the history (nbest_fp8_amax_fold(gamax_new, gamax_prev, 4 L)) and sets fp8_bwd only once a history exists.   */
   const void* w8t;
   const uint32_t* gamax_prev;
   uint32_t* gamax_new;
@@ -444,12 +459,13 @@ typedef struct nbest_encoder_desc {
   /* REQUIRED by nbest_encoder_backward(with_embeddings): token indices of THIS pass sorted by word id (stable), int32 [B*S], device
    * memory - see nbest_embed_ln_bwd.  Set per call like `seed` (it belongs to the batch, not to the shape).                        */
   const int32_t* word_perm;
-  /* fp8 forward: activation amax history, uint32 float bits [4 L]: index 4 l + {0: layer input x (QKV GEMM), 1: ctx (attention-out
-   * GEMM), 2: x1 (FFN-up GEMM), 3: gelu(u) (FFN-down GEMM)}.  Every forward pass RECORDS this pass's amax into aamax_new (when
-   * non-NULL).  With fp8_act != 0 (a history exists in aamax_prev) the producers write e4m3(a * s), s = 2^floor(log2(224 / amax_prev)),
-   * the GEMMs divide by s (and the fp8 weight gradients of the backward, which read the same copies, too); with fp8_act == 0 the
-   * forward is a CALIBRATION pass: it runs the bf16 GEMMs and only records the amax.  The caller swaps prev / new after every
-   * step (after the backward, which reads the copies scaled by prev) and sets fp8_act once a history exists.                     */
+  /* fp8 forward: activation amax history aamax_prev, uint32 float bits [4 L]: index 4 l + {0: layer input x (QKV GEMM), 1: ctx
+   * (attention-out GEMM), 2: x1 (FFN-up GEMM), 3: gelu(u) (FFN-down GEMM)}.  Every forward pass RECORDS this pass's amax into
+   * aamax_new (when non-NULL), a SLOT ARRAY uint32 [4 L][NBEST_AMAX_TENSOR_WORDS] like gamax_new.  With fp8_act != 0 (a history
+   * exists in aamax_prev) the producers write e4m3(a * s), s = 2^floor(log2(224 / amax_prev)), the GEMMs divide by s (and the fp8
+   * weight gradients of the backward, which read the same copies, too); with fp8_act == 0 the forward is a CALIBRATION pass: it
+   * runs the bf16 GEMMs and only records the amax.  After every step (after the backward, which reads the copies scaled by prev)
+   * the caller folds: nbest_fp8_amax_fold(aamax_new, aamax_prev, 4 L), and sets fp8_act once a history exists.                  */
   const uint32_t* aamax_prev;
   uint32_t* aamax_new;
   int32_t fp8_act;

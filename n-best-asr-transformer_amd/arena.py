@@ -109,7 +109,7 @@ class ParamArena:
         self.w16t = None
         self.lazy_w16t = False      # set by the model while its backward runs in fp8: the bf16 transposed copy has no reader then
         self.w16t_stale = False
-        self.w8 = self.w8t = self.w8_inv_scale = self._w8_ws = self.gamax = self.aamax = None
+        self.w8 = self.w8t = self.w8_inv_scale = self._w8_ws = self.gamax = self.aamax = self.gamax_slots = self.aamax_slots = None
         self._tdescs = None
         self.wpk = self.wpkt = None     # packed copies for the bf16 GEMMs (dropped when the fp8 mode is enabled: its GEMMs read w8 / w8t)
         self.w8p = self.w8tp = None
@@ -206,10 +206,13 @@ class ParamArena:
             n = self._tdescs[1]
             self.w8 = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
             self.w8t = torch.zeros(self.total, dtype=torch.uint8, device=self.device)      # transposed: B operand of the fp8 dgrads
-            # gradient amax history of the fp8 dgrads (float bits), two generations swapped by the model after every backward
-            self.gamax = [torch.zeros(n, dtype=torch.int32, device=self.device) for _ in range(2)]
-            # ... and the ACTIVATION amax history of the fp8 forward (x, ctx, x1, gelu(u) per layer), swapped after every step
-            self.aamax = [torch.zeros(n, dtype=torch.int32, device=self.device) for _ in range(2)]
+            # gradient amax history of the fp8 dgrads (float bits) [4 L]: what the next pass reads; and the slot array this pass
+            # records into (include/nbest_hip.h nbest_fp8_amax_fold), folded into the history by the model after every backward
+            self.gamax = torch.zeros(n, dtype=torch.int32, device=self.device)
+            self.gamax_slots = torch.zeros(n * hb.AMAX_TENSOR_WORDS, dtype=torch.int32, device=self.device)
+            # ... and the ACTIVATION amax history of the fp8 forward (x, ctx, x1, gelu(u) per layer), folded after every step
+            self.aamax = torch.zeros(n, dtype=torch.int32, device=self.device)
+            self.aamax_slots = torch.zeros(n * hb.AMAX_TENSOR_WORDS, dtype=torch.int32, device=self.device)
             self.w8_inv_scale = torch.ones(n, dtype=torch.float32, device=self.device)
             self._w8_ws = torch.zeros(4 * n + 16, dtype=torch.uint8, device=self.device)
             # w8 / w8t packed for gemm8_kernel's tiles (nbest_pack_weights_fp8), as wpk / wpkt for the bf16 kernels

@@ -177,6 +177,7 @@ class _Log:
 
 def main(argv=None):
     opt = parse_arguments(argv)
+    trainer.limit_host_threads()
     rank, world, local = trainer.init_distributed()
     dev = torch.device("cuda", local if world > 1 else opt.gpu_index)
     torch.cuda.set_device(dev)

@@ -353,10 +353,16 @@ __device__ __forceinline__ float fp8_grad_scale(const uint32_t* amax_prev) { ret
 // (score floor 8.7e-2 against 6.1e-2) - the bulk paid for headroom the outliers did not need.
 __host__ __device__ __forceinline__ float fp8_ascale_of(float amax) { return fp8_pow2_scale(amax, 224.f); }
 __device__ __forceinline__ float fp8_act_scale(const uint32_t* amax_prev) { return amax_prev ? fp8_ascale_of(__uint_as_float(*amax_prev)) : 1.f; }
-// *p = max(*p, v) for one lane of a wave.  Thousands of waves update the same word: an unconditional atomicMax from each
-// serialises at the L2 (measured: +66 us on a 126 us kernel for 12 288 atomics); reading first lets all but the few waves
-// that actually raise the maximum skip the atomic.
+// Recording a tensor's amax: *slot = max(*slot, v) for one lane of a wave.  An amax "new" pointer names a SLOT BLOCK of
+// NBEST_AMAX_TENSOR_WORDS words (include/nbest_hip.h): kAmaxSlots words 256 bytes apart, one picked by the block index; the
+// caller folds them (nbest_fp8_amax_fold) into the single word the next pass reads.  Why: device-scope accesses to ONE word
+// are served at about 1 ns each wherever they come from - an unconditional atomicMax per wave cost +66 us on a 126 us kernel
+// (12 288 waves), and even with the read-first filter below the 65 536 waves of the e4m3 cast paid 100 us for their reads of
+// the one word (12 -> 115 us; LayerNorm forward +10 us, attention forward +13 us).  Sixteen words in different channels
+// divide that by sixteen; the read-first filter still lets all but the waves that raise their slot skip the atomic.
+constexpr int kAmaxSlots = 16, kAmaxSlotStride = NBEST_AMAX_TENSOR_WORDS / 16;
 __device__ __forceinline__ void amax_update(uint32_t* p, float v) {
+  p += ((blockIdx.x + 5 * blockIdx.y + 3 * blockIdx.z) & (kAmaxSlots - 1)) * kAmaxSlotStride;
   const uint32_t b = __float_as_uint(v);
   if (b > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, b);
 }

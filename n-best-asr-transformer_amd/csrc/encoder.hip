@@ -230,7 +230,7 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
   const bool f8 = fp8_forward_active(d);
   const bool arec = d->w8 && d->aamax_new && d->dtype == NBEST_BF16;     // record the activation amax of this pass (fp8 or calibration)
   auto AP = [&](int idx) -> const uint32_t* { return f8 ? d->aamax_prev + idx : nullptr; };
-  auto AN = [&](int idx) -> uint32_t* { return arec ? d->aamax_new + idx : nullptr; };
+  auto AN = [&](int idx) -> uint32_t* { return arec ? d->aamax_new + (int64_t)idx * NBEST_AMAX_TENSOR_WORDS : nullptr; };   // slot block of tensor idx
   const WsLayout wl = ws_layout(d);
   if (f8) NB_CHECK(ws && ws_bytes >= wl.total, NBEST_ERR_WORKSPACE, "encoder_forward(fp8): workspace too small (%zu < %zu)", ws_bytes, wl.total);
   const Ptrs P{(const char*)wts, prm, a.esz};
@@ -255,11 +255,11 @@ extern "C" int nbest_encoder_forward(const nbest_encoder_desc* d, const void* wt
     if (d->w8p) { g.B_packed = (const uint8_t*)d->w8p + w_off; g.b_pack_bn = nbest_pack_bn_fp8(N, K); }
     g.epilogue = epi; g.out_scale = 1.f; g.out_scale_dev = d->w8_inv_scale + mat; g.drop_p = drop_p; g.drop_stream = stream_id; g.seed = d->seed;
     g.a_amax = d->aamax_prev + mat;         // the A operand's delayed scale (activation index = matrix index: 4 l + {x, ctx, x1, gelu})
-    if (epi == NBEST_EPI_BIAS_GELU) { g.c8_amax_prev = d->aamax_prev + mat + 1; g.c8_amax_new = d->aamax_new ? d->aamax_new + mat + 1 : nullptr; }
+    if (epi == NBEST_EPI_BIAS_GELU) { g.c8_amax_prev = d->aamax_prev + mat + 1; g.c8_amax_new = d->aamax_new ? d->aamax_new + (int64_t)(mat + 1) * NBEST_AMAX_TENSOR_WORDS : nullptr; }
     return nbest_gemm_fp8(&g, stream);
   };
   // calibration pass (fp8 mode without an activation history): bf16 GEMMs, the amax of the four GEMM inputs of every layer recorded
-  auto calib = [&](const void* t, int64_t n, int idx) -> int { return (arec && !f8) ? nbest_internal_amax_bf16(t, n, d->aamax_new + idx, st) : NBEST_OK; };
+  auto calib = [&](const void* t, int64_t n, int idx) -> int { return (arec && !f8) ? nbest_internal_amax_bf16(t, n, d->aamax_new + (int64_t)idx * NBEST_AMAX_TENSOR_WORDS, st) : NBEST_OK; };
   for (int l = 0; l < d->L; ++l) {
     const nbest_layer_offsets& o = d->layers_host[l];
     char* Lb = A + a.layer0 + (size_t)l * a.layer_stride;
@@ -361,7 +361,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
   uint8_t* dRd8 = f8b ? dBig8 + al((size_t)M * F) : nullptr;                 // [M][H]
   auto fg = [&](uint8_t* out8, int idx) -> Fp8Grad {
     if (!rec) return Fp8Grad{nullptr, nullptr, nullptr};
-    return Fp8Grad{f8b ? out8 : nullptr, f8b ? d->gamax_prev + idx : nullptr, d->gamax_new + idx};
+    return Fp8Grad{f8b ? out8 : nullptr, f8b ? d->gamax_prev + idx : nullptr, d->gamax_new + (int64_t)idx * NBEST_AMAX_TENSOR_WORDS};
   };
   auto dgrad8 = [&](const uint8_t* A8, int a_idx, int64_t w_off, int mat, void* Cout, int64_t N, int64_t K, int epi, const void* R,
                     void* U, uint8_t* C8, int c_idx, float* colsum) -> int {
@@ -370,7 +370,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N; g.ldu = N; g.ldc8 = N;
     if (d->w8tp) { g.B_packed = (const uint8_t*)d->w8tp + w_off; g.b_pack_bn = nbest_pack_bn_fp8(N, K); }
     g.epilogue = epi; g.out_scale = 1.f; g.out_scale_dev = d->w8_inv_scale + mat; g.a_amax = d->gamax_prev + a_idx;
-    if (c_idx >= 0) { g.c8_amax_prev = d->gamax_prev + c_idx; g.c8_amax_new = d->gamax_new + c_idx; }
+    if (c_idx >= 0) { g.c8_amax_prev = d->gamax_prev + c_idx; g.c8_amax_new = d->gamax_new + (int64_t)c_idx * NBEST_AMAX_TENSOR_WORDS; }
     g.colsum_out = colsum; g.colsum_accumulate = accumulate; g.ws = red1; g.ws_bytes = w.red_bytes;
     return nbest_gemm_fp8(&g, stream);
   };
@@ -397,7 +397,7 @@ extern "C" int nbest_encoder_backward(const nbest_encoder_desc* d, const void* w
     } else {
       RUN(gemm(dt, dRd, PT.W(o.w2), dBig, M, F, H, H, wt ? H : F, F, 0, tbd, NBEST_EPI_DGELU, nullptr, nullptr, 0, u, F, red1, w.red_bytes, accumulate,
                0.f, 0, 0, st, G(o.b1), PKT(o.w2)));
-      if (rec) RUN(nbest_internal_amax_bf16(dBig, M * F, d->gamax_new + 4 * l + 1, st));   // calibration pass: this producer is a bf16 kernel
+      if (rec) RUN(nbest_internal_amax_bf16(dBig, M * F, d->gamax_new + (int64_t)(4 * l + 1) * NBEST_AMAX_TENSOR_WORDS, st));   // calibration pass: this producer is a bf16 kernel
     }
     stamp(0);
     if (f8b) RUN(nbest_wgrad_fp8(dRd8, h8, G(o.w2), H, F, M, H, F, F, d->gamax_prev + 4 * l + 0, d->aamax_prev + 4 * l + 3, accumulate, slab, w.slab_bytes, stream));

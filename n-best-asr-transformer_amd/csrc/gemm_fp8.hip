@@ -738,6 +738,27 @@ int nbest_internal_amax_bf16(const void* x, int64_t n, uint32_t* out, hipStream_
   return NBEST_OK;
 }
 
+namespace {
+// out[t] = max over the slots of tensor t; the slots are zeroed for the next pass.  One wave per tensor.
+__global__ __launch_bounds__(64) void amax_fold_kernel(uint32_t* __restrict__ slots, uint32_t* __restrict__ out, int n) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  if (t >= n) return;
+  uint32_t* s = slots + (int64_t)t * NBEST_AMAX_TENSOR_WORDS + (lane & (kAmaxSlots - 1)) * kAmaxSlotStride;
+  float v = 0.f;
+  if (lane < kAmaxSlots) { v = __uint_as_float(*s); *s = 0u; }        // (float bits of values >= 0 order like the floats)
+  v = wave_max(v);
+  if (lane == 0) out[t] = __float_as_uint(v);
+}
+}  // namespace
+
+extern "C" int nbest_fp8_amax_fold(void* slots, void* out, int32_t n_tensors, void* stream) {
+  NB_CHECK(slots && out && n_tensors >= 0, NBEST_ERR_ARG, "nbest_fp8_amax_fold: null argument");
+  if (n_tensors == 0) return NBEST_OK;
+  amax_fold_kernel<<<n_tensors, 64, 0, (hipStream_t)stream>>>((uint32_t*)slots, (uint32_t*)out, n_tensors);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
 extern "C" size_t nbest_wgrad_fp8_ws_bytes(int64_t M, int64_t N, int64_t K) {
   int sp; int64_t kps;
   plan8tt(M, N, K, &sp, &kps);

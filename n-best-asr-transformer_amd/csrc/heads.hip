@@ -466,6 +466,19 @@ extern "C" int nbest_cls_mse(const void* hidden_a, int64_t stride_a, const void*
   return NBEST_OK;
 }
 
+namespace {
+__global__ void stamp_kernel(int32_t* flag, int32_t value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+extern "C" int nbest_stream_stamp(int32_t* flag, int32_t value, nbest_stream_t stream) {
+  NB_CHECK(flag, NBEST_ERR_ARG, "stream_stamp: null pointer");
+  stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(flag, value);
+  NB_LAUNCH_CHECK();
+  return NBEST_OK;
+}
+
 extern "C" int nbest_stc_decode(const float* top, const float* bott, const nbest_label_space* ls, const uint8_t* none_flag,
                                 int32_t* pred, int B, nbest_stream_t stream) {
   NB_CHECK(top && bott && ls && none_flag && pred && B > 0, NBEST_ERR_ARG, "stc_decode: null pointer");

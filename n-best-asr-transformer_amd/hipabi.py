@@ -19,7 +19,7 @@ EXPORTS = [
     "nbest_version", "nbest_last_error", "nbest_embed_ln_fwd", "nbest_embed_ln_bwd", "nbest_embed_bwd_ws_bytes", "nbest_rows_gather", "nbest_rows_zero", "nbest_rows_add",
     "nbest_gemm_ws_bytes", "nbest_gemm", "nbest_wgrad_pair_ws_bytes", "nbest_wgrad_pair", "nbest_pack_bn", "nbest_pack_weights", "nbest_pack_bn_fp8", "nbest_pack_weights_fp8", "nbest_attention_fwd", "nbest_attention_bwd", "nbest_attention_bwd_ws_bytes", "nbest_attention_keep_bytes", "nbest_attention_fwd_keep", "nbest_attention_bwd_keep", "nbest_layernorm_fwd",
     "nbest_layernorm_bwd", "nbest_rowred_ws_bytes", "nbest_colsum", "nbest_heads_ws_bytes", "nbest_stc_heads",
-    "nbest_stc_heads_vjp", "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
+    "nbest_stc_heads_vjp", "nbest_cls_mse", "nbest_cls_grad_scatter", "nbest_stc_decode", "nbest_stream_stamp", "nbest_fp8_amax_fold", "nbest_bertadam_chunk", "nbest_bertadam_step", "nbest_bertadam_norms", "nbest_bertadam_update",
     "nbest_cast_f32_to_bf16", "nbest_transpose_weights", "nbest_encoder_act_bytes", "nbest_encoder_ws_bytes", "nbest_encoder_wgrad_launches_per_layer", "nbest_encoder_forward",
     "nbest_encoder_backward", "nbest_gemm_fp8", "nbest_gemm_fp8_ws_bytes", "nbest_wgrad_fp8", "nbest_wgrad_fp8_ws_bytes", "nbest_wgrad_fp8_pair", "nbest_wgrad_fp8_pair_ws_bytes", "nbest_cast_bf16_to_fp8", "nbest_quantize_weights_fp8",
 ]
@@ -127,6 +127,8 @@ def lib():
         L.nbest_cls_mse.argtypes = [vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, f32, vp]
         L.nbest_cls_grad_scatter.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.nbest_stc_decode.argtypes = [vp, vp, C.POINTER(LabelSpaceC), vp, vp, i32, vp]
+        L.nbest_stream_stamp.argtypes = [vp, i32, vp]
+        L.nbest_fp8_amax_fold.argtypes = [vp, vp, i32, vp]
         L.nbest_bertadam_step.argtypes = [vp] * 6 + [i32, i32, f32, f32, f32, f32, f32, vp, sz, vp]
         L.nbest_bertadam_norms.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
         L.nbest_bertadam_update.argtypes = [vp] * 6 + [i32, i32, i32, i32, vp, vp, f32, f32, f32, f32, f32, vp]
@@ -540,11 +542,33 @@ def stc_heads(hidden, cls_stride, Wh, bh, dls, labels_f, B, H, need_grad=True, a
     return top, bott, fin, loss, dcls, dWh, dbh
 
 
-def stc_decode(top, bott, dls):
+def stc_decode(top, bott, dls, out=None):
+    """``out``: int32 [>= B, n_top] rows to decode into instead of a fresh device tensor - a PINNED host tensor makes the kernel
+    write the rows straight into host memory (include/nbest_hip.h nbest_stc_decode)"""
     B = top.shape[0]
-    pred = torch.empty(B, dls.labels.n_top, dtype=torch.int32, device=top.device)
+    if out is None:
+        pred = torch.empty(B, dls.labels.n_top, dtype=torch.int32, device=top.device)
+    else:
+        assert out.dtype == torch.int32 and out.is_contiguous() and out.shape[0] >= B and out.shape[1] == dls.labels.n_top
+        assert out.is_cuda or out.is_pinned(), "stc_decode: out must be device memory or pinned host memory"
+        pred = out[:B]
     check(lib().nbest_stc_decode(ptr(top), ptr(bott), C.byref(dls.c), ptr(dls.none_flag), ptr(pred), B, stream_ptr()), "stc_decode")
     return pred
+
+
+def stream_stamp(flag, value):
+    """*flag = value in stream order (flag: one int32 of device or PINNED host memory)"""
+    assert flag.dtype == torch.int32 and flag.numel() == 1 and (flag.is_cuda or flag.is_pinned())
+    check(lib().nbest_stream_stamp(ptr(flag), int(value), stream_ptr()), "stream_stamp")
+
+
+AMAX_TENSOR_WORDS = 1024        # include/nbest_hip.h NBEST_AMAX_TENSOR_WORDS
+
+
+def fp8_amax_fold(slots, out):
+    """out[t] = max over the recording slots of tensor t; the slots are zeroed (nbest_fp8_amax_fold)"""
+    assert slots.numel() == out.numel() * AMAX_TENSOR_WORDS and slots.dtype == out.dtype == torch.int32
+    check(lib().nbest_fp8_amax_fold(ptr(slots), ptr(out), out.numel(), stream_ptr()), "fp8_amax_fold")
 
 
 def cls_mse(hidden_a, stride_a, hidden_t, stride_t, B, H, da=None, dt=None, grad_scale=1.0):

@@ -183,23 +183,35 @@ def encode_utterance(seq, tokenizer, opt, n_best=None, max_seq_len=None):
     return tokenizer.convert_tokens_to_ids(toks), seg
 
 
-def collate(rows, pad_id, pin=False):
+def collate(rows, pad_id, pin=False, alloc=None):
     """[(ids, seg | None)] -> right-padded int64 host tensors ``ids [B,S]``, ``seg [B,S] | None`` and the lengths
     (bert_xlnet_inputs.py:87-102: pad id for ids, 0 for segments, width = batch maximum).  One masked numpy assignment per
     tensor (round 3 copied row by row through torch.as_tensor: 18 ms per 256-utterance batch - with the real-data loop's
-    prefetch thread sharing the interpreter lock with the training loop, that was most of a step)."""
+    prefetch thread sharing the interpreter lock with the training loop, that was most of a step).
+    ``alloc(which, shape)`` -> an int64 host tensor of that shape to fill (``which`` 0 ids, 1 segments): the prefetcher hands out
+    slices of long-lived PINNED staging buffers instead of a fresh pin_memory() per tensor per batch (trainer.PinnedStage)."""
     import numpy as np
     lens = [len(r[0]) for r in rows]
     width = max(lens)
     inside = np.arange(width)[None, :] < np.asarray(lens)[:, None]
-    ids = np.full((len(rows), width), pad_id, dtype=np.int64)
-    ids[inside] = np.concatenate([np.asarray(r[0], dtype=np.int64) for r in rows])
-    seg = None
-    if rows[0][1] is not None:
-        seg = np.zeros((len(rows), width), dtype=np.int64)
-        seg[inside] = np.concatenate([np.asarray(r[1], dtype=np.int64) for r in rows])
-    to_t = (lambda a: torch.from_numpy(a).pin_memory()) if pin else torch.from_numpy
-    return to_t(ids), (None if seg is None else to_t(seg)), lens
+
+    def filled(which, value, col):
+        if alloc is None:
+            a = np.full((len(rows), width), value, dtype=np.int64)
+            t = None
+        else:
+            t = alloc(which, (len(rows), width))
+            a = t.numpy()
+            a.fill(value)
+        a[inside] = np.concatenate([np.asarray(r[col], dtype=np.int64) for r in rows])
+        if t is None:
+            t = torch.from_numpy(a)
+            t = t.pin_memory() if pin else t
+        return t
+
+    ids = filled(0, pad_id, 0)
+    seg = filled(1, 0, 1) if rows[0][1] is not None else None
+    return ids, seg, lens
 
 
 def prepare_inputs_for_roberta(raw_in, tokenizer, opt, device, n_best=None, max_seq_len=None):

@@ -155,12 +155,10 @@ class NBestSTCModel(nn.Module):
         # (dgrad) / the e4m3 activation copies the forward stashed per layer (wgrad, fp32 out); the first backward pass runs the
         # bf16 GEMMs and only records the amax history.
         self.fp8_backward = self.fp8_forward if fp8_backward is None else bool(fp8_backward)
-        self._gamax_gen = 0                # which of arena.gamax[0/1] holds the previous pass's amax
         self._gamax_valid = False
         # ... and the forward's four GEMM inputs per layer (x, ctx, x1, gelu(u)) are e4m3 copies with a DELAYED per-tensor scale
         # 2^floor(log2(224 / amax of the same tensor in the previous step)); the first step after (re)loading weights is a
         # calibration step: bf16 GEMMs, amax recorded (round 3 cast activations at unit scale and saturated silently beyond 448)
-        self._aamax_gen = 0
         self._aamax_valid = False
         self._step_fp8_fwd = False         # did the forward of the running step run in fp8 (its backward may then, too)
         if self.fp8_forward:
@@ -196,12 +194,12 @@ class NBestSTCModel(nn.Module):
         bf16 GEMMs and records a fresh one (as the very first pass does)"""
         if self.fp8_backward and self._gamax_valid:
             self._gamax_valid = False
-            for t in self.arena.gamax:
-                t.zero_()
+            self.arena.gamax.zero_()
+            self.arena.gamax_slots.zero_()
         if self.fp8_forward and self._aamax_valid:
             self._aamax_valid = False
-            for t in self.arena.aamax:
-                t.zero_()
+            self.arena.aamax.zero_()
+            self.arena.aamax_slots.zero_()
 
     def load_reference_state(self, sd, strict=True):
         self._drop_fp8_history()
@@ -329,19 +327,18 @@ class NBestSTCModel(nn.Module):
         """activation amax history of the fp8 forward: the same two generations for every pass of a step (ASR + transcript pass
         record into the same words: the next step's scale covers both)"""
         a = self.arena
-        d.aamax_prev, d.aamax_new = a.aamax[self._aamax_gen].data_ptr(), a.aamax[1 - self._aamax_gen].data_ptr()
+        d.aamax_prev, d.aamax_new = a.aamax.data_ptr(), a.aamax_slots.data_ptr()
         d.fp8_act = int(self._aamax_valid)
         self._step_fp8_fwd = self._aamax_valid
 
     def _end_of_step_fp8(self, ran_backward):
-        """this step's amax words become the history of the next one (after the backward: it reads the forward's scaled copies)"""
+        """this step's recorded amax (slots) becomes the history of the next one - after the backward, which reads the forward's
+        copies scaled by the old history"""
         if self.fp8_forward:
-            self._aamax_gen = 1 - self._aamax_gen
-            self.arena.aamax[1 - self._aamax_gen].zero_()
+            hb.fp8_amax_fold(self.arena.aamax_slots, self.arena.aamax)
             self._aamax_valid = True
         if ran_backward and self.fp8_backward:
-            self._gamax_gen = 1 - self._gamax_gen
-            self.arena.gamax[1 - self._gamax_gen].zero_()
+            hb.fp8_amax_fold(self.arena.gamax_slots, self.arena.gamax)
             self._gamax_valid = True
 
     def _set_fp8_backward(self, d):
@@ -349,7 +346,7 @@ class NBestSTCModel(nn.Module):
         if self.fp8_backward:
             a = self.arena
             d.w8t = a.w8t.data_ptr()
-            d.gamax_prev, d.gamax_new = a.gamax[self._gamax_gen].data_ptr(), a.gamax[1 - self._gamax_gen].data_ptr()
+            d.gamax_prev, d.gamax_new = a.gamax.data_ptr(), a.gamax_slots.data_ptr()
             on = self._gamax_valid and self._aamax_valid      # the fp8 weight gradients read the fp8 forward's activation copies
             d.fp8_bwd = int(on)
             a.lazy_w16t = on                      # steady state: every dgrad reads w8t, nobody reads the bf16 transposed copy
@@ -360,9 +357,8 @@ class NBestSTCModel(nn.Module):
         if self.arena.w16t_stale and not (self.fp8_backward and self._gamax_valid and self._aamax_valid):
             self.arena.refresh_w16t()             # a bf16 backward after fp8 steps (history dropped, mode switched)
         self._set_packed(ps.desc)
-        # gradient w.r.t. the final hidden states [B*S, H] (zero except the CLS rows): ONE grow-only buffer, like the activation stash -
-        # real batches change shape every step, and a fresh 40-50 MB tensor of a new size per step sends the caching allocator to
-        # hipMalloc / hipFree (a device synchronisation) over and over
+        # gradient w.r.t. the final hidden states [B*S, H] (zero except the CLS rows): ONE grow-only buffer, like the activation stash
+        # (real batches change shape every step: no fresh 40-50 MB tensor of a new size per step through the caching allocator)
         n_dh = ps.B * ps.S * cfg.hidden_size
         if self._dh is None or self._dh.numel() < n_dh:
             self._dh = None
@@ -478,9 +474,9 @@ class NBestSTCModel(nn.Module):
         return dict(top=top, bott=bott, final=fin, loss_parts=loss, asr_cls=ha.view(B, S, H)[:, 0, :],
                     trans_cls=None if ht is None else ht.view(B, St, H)[:, 0, :])
 
-    def decode(self, top, bott):
-        """device decode of pred_one_sample -> int32 [B, n_top] bottom-label index or -1"""
-        return hb.stc_decode(top, bott, self.dls)
+    def decode(self, top, bott, out=None):
+        """device decode of pred_one_sample -> int32 [B, n_top] bottom-label index or -1 (``out``: see hipabi.stc_decode)"""
+        return hb.stc_decode(top, bott, self.dls, out=out)
 
 
 def make_model(opt):

@@ -356,42 +356,54 @@ def _host_metrics(model, out, raw_labels, idx2label, counts, ontology=None):
 
 
 class MetricsPipe:
-    """The per-sample decode of the reference (n_best_asr_bert.py:283-288) WITHOUT a host synchronisation per step: round 3 did
+    """The per-sample decode of the reference (n_best_asr_bert.py:283-288) WITHOUT a host synchronisation per step.  Round 3 did
     ``model.decode(...).cpu().tolist()`` after every step, which drains the compute stream - the GPU then idles while Python
-    prepares the next step.  Here the device decode of step i is enqueued on the compute stream, its int32 [B, 30] result travels
-    to pinned host memory on a side stream behind an event, and the host turns it into labels / F1 counts one step LATER (while
-    step i + 1 runs); ``finish()`` drains the last one.  Same counts, same order."""
+    prepares the next step.  Here the decode kernel of step i writes its int32 [B, 30] rows STRAIGHT into one of two pinned host
+    buffers (mapped host memory: no copy command), a one-thread kernel behind it stamps the step number into a pinned word
+    (nbest_stream_stamp), and the host turns the rows into labels / F1 counts one step LATER, after polling that word - while
+    step i + 1 runs.  No hipMemcpy, no event, no stream synchronisation.  (tools/real_variants.py times this form against a
+    non_blocking D2H copy + event wait: once the host thread pool is capped - limit_host_threads, the actual cause of the 37 ms
+    steps first measured - both keep the GPU busy, 20.4 vs 20.5 ms per step; this one issues no runtime call besides the two
+    launches.)  ``finish()`` drains the last one.  Same counts, same order."""
 
     def __init__(self, model, idx2label, ontology=None):
         self.model, self.idx2label, self.ontology = model, idx2label, ontology
         self.counts, self.preds = (0, 0, 0, 0, 0), []
         self.cuda = model.device.type == "cuda"
-        self.side = torch.cuda.Stream(model.device) if self.cuda else None
+        self.bufs, self.turn, self.seq = [None, None], 0, 0
+        self.flags = torch.zeros(2, dtype=torch.int32).pin_memory() if self.cuda else None
         self.pending = None
 
+    def _host_rows(self, B, n_top):
+        """one of two alternating pinned buffers, grown when a larger batch comes (never reallocated per step)"""
+        t = self.turn = self.turn ^ 1
+        if self.bufs[t] is None or self.bufs[t].shape[0] < B or self.bufs[t].shape[1] != n_top:
+            self.bufs[t] = torch.empty(B, n_top, dtype=torch.int32).pin_memory()
+        return t, self.bufs[t]
+
     def push(self, out, raw_labels, tag=None):
-        pred = self.model.decode(out["top"], out["bott"])
         if not self.cuda:
-            self._consume((pred, None, raw_labels, tag))
+            self._consume((self.model.decode(out["top"], out["bott"]), None, raw_labels, tag))
             return
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(self.model.device))
-        host = torch.empty(pred.shape, dtype=pred.dtype).pin_memory()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            host.copy_(pred, non_blocking=True)
-            pred.record_stream(self.side)
-            done = torch.cuda.Event()
-            done.record(self.side)
-        prev, self.pending = self.pending, (host, done, raw_labels, tag)
+        # (buffer t held step i-2, whose rows were counted at the previous push)
+        t, rows = self._host_rows(out["top"].shape[0], out["top"].shape[1])
+        pred = self.model.decode(out["top"], out["bott"], out=rows)
+        self.seq += 1
+        hb.stream_stamp(self.flags[t:t + 1], self.seq)
+        prev, self.pending = self.pending, (pred, (t, self.seq), raw_labels, tag)
         if prev is not None:
             self._consume(prev)
 
     def _consume(self, item):
-        host, done, raw_labels, tag = item
-        if done is not None:
-            done.synchronize()                 # the side stream's copy only: the compute stream keeps running the next step
-        self.counts, preds = _count_metrics(host.cpu().tolist(), raw_labels, self.idx2label, self.counts, self.ontology)
+        host, stamp, raw_labels, tag = item
+        if stamp is not None:
+            t, seq = stamp
+            flag, t0 = self.flags.numpy(), time.time()
+            while flag[t] != seq:              # step i-1's rows: the compute stream already holds step i
+                time.sleep(0.0002)
+                if time.time() - t0 > 600.0:
+                    raise RuntimeError("nbest_amd: the decode of a step did not arrive within 10 minutes")
+        self.counts, preds = _count_metrics(host.tolist(), raw_labels, self.idx2label, self.counts, self.ontology)
         self.preds.append((tag, preds))
 
     def finish(self):
@@ -430,21 +442,84 @@ class EncodedSplit:
     def __len__(self):
         return len(self.asr)
 
-    def host_batch(self, idx, pin=False):
-        ids, seg, _ = collate([self.rows[j] for j in idx], self.pad, pin)
-        tids, tseg, _ = collate([self.trows[j] for j in idx], self.pad, pin)
-        y = self.y[torch.as_tensor(idx, dtype=torch.long)]
+    def host_batch(self, idx, pin=False, stage=None):
+        """``stage``: a PinnedStage whose buffers receive every tensor of the batch (no allocation per batch)"""
+        take = (lambda name: (lambda which, shape: stage.take(name + str(which), shape, torch.int64))) if stage is not None else (lambda name: None)
+        ids, seg, _ = collate([self.rows[j] for j in idx], self.pad, pin and stage is None, alloc=take("a"))
+        tids, tseg, _ = collate([self.trows[j] for j in idx], self.pad, pin and stage is None, alloc=take("t"))
         # rows of the word-embedding table this batch touches (sparse gradient exchange under data parallelism)
-        rows = torch.from_numpy(np.unique(np.concatenate([ids.numpy().ravel(), tids.numpy().ravel()])))
+        rows = np.unique(np.concatenate([ids.numpy().ravel(), tids.numpy().ravel()]))
         # tokens sorted by word id, ties in token order: what the deterministic embedding backward reduces over (nbest_embed_ln_bwd)
-        perm, tperm = token_perm(ids), token_perm(tids)
-        p_ = (lambda t: t.pin_memory()) if pin else (lambda t: t)
-        return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=p_(y), word_rows=p_(rows), tok_perm=p_(perm), ttok_perm=p_(tperm))
+        perm, tperm = token_perm(ids, as_numpy=True), token_perm(tids, as_numpy=True)
+        if stage is None:
+            p_ = (lambda t: t.pin_memory()) if pin else (lambda t: t)
+            y = p_(self.y[torch.as_tensor(idx, dtype=torch.long)])
+            rows, perm, tperm = p_(torch.from_numpy(rows)), p_(torch.from_numpy(perm)), p_(torch.from_numpy(tperm))
+        else:
+            y = stage.take("y", (len(idx), self.y.shape[1]), self.y.dtype)
+            np.take(self.y.numpy(), np.asarray(idx, dtype=np.int64), axis=0, out=y.numpy())   # (numpy: no torch CPU thread pool in the worker)
+            rows, perm, tperm = stage.put("rows", rows, torch.int64), stage.put("perm", perm, torch.int32), stage.put("tperm", tperm, torch.int32)
+        return dict(ids=ids, seg=seg, tids=tids, tseg=tseg, labels=y, word_rows=rows, tok_perm=perm, ttok_perm=tperm)
 
 
-def token_perm(ids):
+_ITEMSIZE = {torch.int64: 8, torch.int32: 4, torch.float32: 4, torch.uint8: 1}
+
+
+def host_cpu_budget():
+    """CPUs this process may really use: the smaller of its affinity mask and its cgroup quota (cpu.max / cfs_quota_us)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(quota) // int(period)))
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def limit_host_threads():
+    """torch sizes its CPU thread pool by the MACHINE's cores (128 on the GPU box) while the container's quota is 16: every small
+    CPU op of the loop (an index_select of the label rows: 5.6 ms instead of 0.05) wakes 128 spinning threads, the cgroup is
+    throttled and the whole process - the thread that launches kernels included - is frozen for the rest of the scheduling
+    period.  Measured on the box (tools/host_batch_time.py): a prefetched batch cost 6.8 ms of host time at 128 threads, 0.9 ms
+    at one; inside the training loop 23-47 ms, more than a step.  The HIP path needs no CPU parallelism: cap the pool at the
+    smaller of 4 and the quota.  Called by the epoch loops' Prefetcher (both of its threads), cli.py and bench.py."""
+    want = max(1, min(4, host_cpu_budget()))
+    if torch.get_num_threads() > want:
+        torch.set_num_threads(want)
+
+
+class PinnedStage:
+    """Long-lived pinned host buffers for ONE batch in flight, by name, grown geometrically when a larger batch comes.
+    ``take(name, shape, dtype)`` -> a tensor view to fill; ``put(name, array, dtype)`` copies a numpy array in."""
+
+    def __init__(self, pin=True):
+        self.pin, self.buf = pin, {}
+
+    def take(self, name, shape, dtype):
+        n = int(np.prod(shape)) * _ITEMSIZE[dtype]
+        t = self.buf.get(name)
+        if t is None or t.numel() < n:
+            t = torch.empty(max(n, 2 * (0 if t is None else t.numel()), 4096), dtype=torch.uint8)
+            t = self.buf[name] = t.pin_memory() if self.pin else t
+        return t[:n].view(dtype).view(*shape)
+
+    def put(self, name, array, dtype):
+        t = self.take(name, array.shape, dtype)
+        t.numpy()[...] = array
+        return t
+
+
+def token_perm(ids, as_numpy=False):
     """host: int32 [B*S] token indices sorted by word id, ties in ascending token index (numpy's stable argsort)"""
-    return torch.from_numpy(np.argsort(ids.reshape(-1).numpy(), kind="stable").astype(np.int32))
+    p = np.argsort(ids.reshape(-1).numpy(), kind="stable").astype(np.int32)
+    return p if as_numpy else torch.from_numpy(p)
 
 
 def encoded(data, opt, memory):
@@ -471,26 +546,42 @@ class Prefetcher:
         self.cuda = self.device.type == "cuda"
         self.q = queue.Queue(maxsize=depth)
         self.stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.seconds = [0.0, 0.0, 0.0]
+        limit_host_threads()
+        # pinned staging: one PinnedStage per batch that can be alive at once (depth in the queue + the one the consumer holds + the one
+        # being built + one spare), reused round-robin once the H2D copies that read it have completed
+        self.stages = [(PinnedStage(), [None]) for _ in range(depth + 3)] if self.cuda else None
         self.thread = threading.Thread(target=self._work, daemon=True)
         self.thread.start()
 
     def _work(self):
         try:
+            limit_host_threads()                                     # (OpenMP's thread count is a per-thread setting)
             for bi, idx in enumerate(self.lists):
                 lo, hi = shard_bounds(len(idx), self.rank, self.world)
                 if hi <= lo:
                     self.q.put((bi, [], None, None))                 # nothing for this rank in this batch
                     continue
                 mine = idx[lo:hi]
-                host = self.split.host_batch(mine, pin=self.cuda)
+                t0 = time.time()
                 if not self.cuda:
-                    self.q.put((bi, mine, host, None))
+                    self.q.put((bi, mine, self.split.host_batch(mine), None))
                     continue
+                stage, last = self.stages[bi % len(self.stages)]
+                if last[0] is not None:
+                    last[0].synchronize()                             # the copies out of this stage, depth + 3 batches ago
+                host = self.split.host_batch(mine, stage=stage)
+                t1 = time.time()
                 with torch.cuda.stream(self.stream):
                     dev = {k: (None if v is None else v.to(self.device, non_blocking=True)) for k, v in host.items()}
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
-                self.q.put((bi, mine, dev, (ev, host)))              # host buffers stay alive until the copy was waited on
+                last[0] = ev
+                t2 = time.time()
+                self.q.put((bi, mine, dev, (ev, host)))
+                self.seconds[0] += t1 - t0                           # (worker-side clock: collate | H2D enqueue | queue full)
+                self.seconds[1] += t2 - t1
+                self.seconds[2] += time.time() - t2
             self.q.put(None)
         except BaseException as e:                                   # surface worker failures in the consumer
             self.q.put(e)

@@ -195,6 +195,14 @@ def test_encoded_split_and_prefetcher_match_per_batch_builder(labels):
                 assert torch.equal(b["labels"], y)
                 seen += 1
             assert seen == len(lists)
+    # the GPU loop's staging path: every tensor of a batch written into long-lived (there: pinned) buffers, reused batch after batch -
+    # the same tensors as the allocating path, also when a LARGER batch follows a smaller one in the same stage
+    stage = trainer.PinnedStage(pin=False)
+    for idx in ([3], lists[0], lists[1][:2], list(range(24))):
+        a, b = split.host_batch(idx), split.host_batch(idx, stage=stage)
+        assert a.keys() == b.keys()
+        for k in a:
+            assert (a[k] is None and b[k] is None) or (a[k].dtype == b[k].dtype and torch.equal(a[k], b[k])), k
     # a rank with an empty slice still sees the batch (it must join that step's collectives)
     got = [(bi, mine) for bi, mine, _ in trainer.Prefetcher(split, [[0], [1, 2]], "cpu", 1, 2)]
     assert got == [(0, []), (1, [2])]

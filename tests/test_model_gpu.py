@@ -458,10 +458,10 @@ def test_fp8w_gradient_amax_jump(labels):
         return w
     m.forward_backward(b["ids"], b["labels"], **kw)                                  # calibration pass: bf16 backward, records amax
     m.forward_backward(b["ids"], b["labels"], **kw)                                  # fp8 backward, history = own amax
-    a1 = m.arena.gamax[m._gamax_gen].clone().view(torch.float32)
+    a1 = m.arena.gamax.clone().view(torch.float32)
     w1 = worst(1.0)
     m.forward_backward(b["ids"], b["labels"], encoder_grad_scale=8.0, **kw)          # every gradient amax jumps 8 x against its history
-    a8 = m.arena.gamax[m._gamax_gen].clone().view(torch.float32)
+    a8 = m.arena.gamax.clone().view(torch.float32)
     w8 = worst(8.0)
     live = a1 > 0
     jump = (a8[live] / a1[live])

@@ -53,7 +53,8 @@ import statistics
 lists = trainer.batch_indices(len(split), 256, shuffle=True, seed=5)
 host, gpu = [], []
 pf = trainer.Prefetcher(split, lists, m.device, 0, 1)
-prev_end = None
+torch.cuda.synchronize()
+t_loop = time.time()
 for bi, mine, b in pf:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -63,6 +64,7 @@ for bi, mine, b in pf:
     e1.record()
     gpu.append((e0, e1))
 torch.cuda.synchronize()
+print("train_step only loop: %.1f ms per step (wall)" % ((time.time() - t_loop) * 1e3 / len(lists)))
 g = [a.elapsed_time(b_) for a, b_ in gpu]
 print("train_step only, no metrics: host enqueue %.1f ms median (max %.1f); GPU step %.1f ms median (max %.1f)" % (
     statistics.median(host), max(host), statistics.median(g), max(g)))
