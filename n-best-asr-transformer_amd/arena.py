@@ -127,24 +127,31 @@ class ParamArena:
                 t += ((r + 63) // 64) * ((c + 63) // 64)
             self._tdescs = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(mats), t)
             # the same matrices PACKED for the k-contiguous GEMM kernels (nbest_pack_weights): wpk from w16 ([out][in], forward GEMMs),
-            # wpkt from w16t ([in][out], dgrad GEMMs); a matrix whose shape has no packed form is left out of both tables (the GEMMs
-            # then read w16 / w16t - encoder.hip asks nbest_pack_bn the same question)
-            self.wpk = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
-            self.wpkt = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+            # wpkt from w16t ([in][out], dgrad GEMMs).  All or nothing: encoder.hip hands `wpk + offset` to EVERY GEMM of a layer, so as
+            # soon as one matrix has no packed form (nbest_pack_bn == 0: e.g. H = 512, whose widths are neither multiples of 192 nor
+            # >= 1024 multiples of 256) both tables are dropped and every GEMM reads w16 / w16t row by row - same results.
             self._pdescs = []
             for transposed in (False, True):
                 sel = []
                 for off, r, c in mats:
                     n, k = (c, r) if transposed else (r, c)
                     bn = hb.lib().nbest_pack_bn(n)
-                    assert bn > 0 and k % 32 == 0 and n % bn == 0, "encoder matrix %d x %d has no packed form" % (n, k)
+                    if not (bn > 0 and k % 32 == 0 and n % bn == 0):
+                        sel = None
+                        break
                     sel.append((off, n, k, bn))
+                if sel is None:
+                    self._pdescs = None
+                    break
                 parr = (hb.MatrixDesc * len(sel))()
                 t = 0
                 for i, (off, n, k, bn) in enumerate(sel):
                     parr[i].offset, parr[i].rows, parr[i].cols, parr[i].tile_start, parr[i].pad = off, n, k, t, bn
                     t += (n // bn) * (k // 32)
                 self._pdescs.append((torch.frombuffer(bytearray(bytes(parr)), dtype=torch.uint8).to(self.device), len(sel), t))
+            if self._pdescs is not None:
+                self.wpk = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+                self.wpkt = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
         self._descs = None
 
     # ---- views ---------------------------------------------------------------------------------
@@ -216,8 +223,6 @@ class ParamArena:
             self.w8_inv_scale = torch.ones(n, dtype=torch.float32, device=self.device)
             self._w8_ws = torch.zeros(4 * n + 16, dtype=torch.uint8, device=self.device)
             # w8 / w8t packed for gemm8_kernel's tiles (nbest_pack_weights_fp8), as wpk / wpkt for the bf16 kernels
-            self.w8p = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
-            self.w8tp = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
             H, F = self.cfg.hidden_size, self.cfg.intermediate_size
             mats = []
             for o in self.layer_offsets:
@@ -229,10 +234,19 @@ class ParamArena:
                 for i, (off, r, c) in enumerate(mats):
                     nn, kk = (c, r) if transposed else (r, c)
                     bn = hb.lib().nbest_pack_bn_fp8(nn, kk)
-                    assert bn > 0 and kk % 64 == 0 and nn % bn == 0, "encoder matrix %d x %d has no packed e4m3 form" % (nn, kk)
+                    if not (bn > 0 and kk % 64 == 0 and nn % bn == 0):       # all or nothing, as for wpk / wpkt above
+                        parr = None
+                        break
                     parr[i].offset, parr[i].rows, parr[i].cols, parr[i].tile_start, parr[i].pad = off, nn, kk, t, bn
                     t += (nn // bn) * (kk // 64)
+                if parr is None:
+                    self._p8descs = None
+                    break
                 self._p8descs.append((torch.frombuffer(bytearray(bytes(parr)), dtype=torch.uint8).to(self.device), len(mats), t))
+            self.w8p = self.w8tp = None
+            if self._p8descs is not None:
+                self.w8p = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
+                self.w8tp = torch.zeros(self.total, dtype=torch.uint8, device=self.device)
             self.refresh_transposed()
 
     def load_state(self, sd, strict=True):

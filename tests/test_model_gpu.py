@@ -714,6 +714,40 @@ def test_packed_weight_operands_change_nothing(labels):
     assert res[0][2].abs().max() > 0
 
 
+def test_width_without_packed_form_uses_plain_operands(labels):
+    """a bf16 model whose matrix widths have no packed form (H = 512: the N = 512 GEMMs are neither multiples of 192 nor
+    >= 1024 multiples of 256) must construct - round 3 asserted in ParamArena - and run with BOTH packed tables dropped (the C side hands
+    `wpk + offset` to every GEMM of a layer, so a partly filled table would be read as zeros): one step of the bf16 path lands on the fp32
+    path's loss and gradient like any other width."""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    cfg = ncfg.bert_base(num_hidden_layers=2, hidden_size=512, num_attention_heads=8, intermediate_size=2048, vocab_size=3000,
+                         hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = synth.model_state(cfg, labels, seed=6)
+    b = synth.nbest_batch(cfg, labels, 64, 96, n_best=5, seed=23, ragged=True)
+    t = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dt, dropout=0.0)
+        if dt == torch.bfloat16:
+            assert m.arena.wpk is None and m.arena.wpkt is None and m.arena.w16t is not None
+        m.load_reference_state(sd)
+        m.train()
+        out = m.forward_backward(t["ids"], t["labels"], seg_ids=t["seg"])
+        torch.cuda.synchronize()
+        res[dt] = (out["loss_parts"].sum().item(), m.arena.view(m.arena.g, "bert_encoder.encoder.layer.0.output.dense.weight").clone(),
+                   out["final"].clone())
+    l32, g32, f32_ = res[torch.float32]
+    l16, g16, f16_ = res[torch.bfloat16]
+    assert abs(l16 - l32) <= 2e-3 * abs(l32), (l16, l32)
+    assert (f16_ - f32_).abs().max().item() <= 1e-2
+    ns = ((g16 - g32).norm() / g32.norm()).item()
+    _log("H = 512 (no packed form): bf16 vs fp32 loss %.6f / %.6f, final scores %.2e, FFN-down gradient noise-to-signal %.2e" % (
+        l16, l32, (f16_ - f32_).abs().max().item(), ns))
+    assert g32.abs().max() > 0 and ns <= 2e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "fp8w"])
 def test_training_trajectory_tracks_oracle(dtype, labels):
     """eight optimisation steps (forward, BCE / CE / CLS-MSE losses, backward, BertAdam with warm-up) on changing batches:
