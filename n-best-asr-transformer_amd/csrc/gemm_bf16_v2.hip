@@ -251,6 +251,59 @@ __device__ __forceinline__ void pp_mfma_slot(const bf16x8* af, const bf16x8* bfr
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- helpers of the stripped ping-pong loop of the weight-gradient (TN) kernel: both operands token-major, fragments by transposed reads.
+// LDS image of one operand ring (STAGES stages of ROWS x 32 k): [16 k-row pairs][STAGES][2 k-rows x ROWS * 2 B] - the ring index sits
+// BELOW the k-row pair, so that (a) an LDS-DMA wave-instruction (1 KiB = 2 k-rows of 256 features) still writes contiguously and (b) the
+// stage offset (1 KiB x stage) and the upper half's offset of a fragment fit the 16-bit immediate of ds_read: a fragment address is ONE
+// per-lane register computed before the loop + an immediate.  Inside a k-row the 16-byte chunk swizzle of stage_tile2<true> is unchanged
+// (a k-row starts at a multiple of 512 B in either layout: same banks).
+template <int OFF> __device__ __forceinline__ bf16x4 ds_read_tr_off(uint32_t a) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+template <int B_, int STAGES, int NF>
+__device__ __forceinline__ void tt_frags(const uint32_t* base, bf16x8* fr) {
+  constexpr int HALF = 2 * STAGES * 1024;      // k-rows + 4: two k-row pairs further
+#pragma unroll
+  for (int t = 0; t < NF; ++t) {
+    const bf16x4 lo = ds_read_tr_off<B_ * 1024>(base[t]);
+    const bf16x4 hi = ds_read_tr_off<B_ * 1024 + HALF>(base[t]);
+    fr[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+// LDS-DMA of one stage of both operands into ring slot NB_: wave wv issues pieces (i * 8 + wv), i = 0, 1, of each operand
+template <int NB_, int STAGES>
+__device__ __forceinline__ void tt_issue(__amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, char* ldsA, char* ldsB, const uint32_t* voA,
+                                         const uint32_t* voB, int wv) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(ldsA + ((i * 8 + wv) * STAGES + NB_) * 1024), 16, voA[i], 0, 0, NB_AUX_A);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(ldsB + ((i * 8 + wv) * STAGES + NB_) * 1024), 16, voB[i], 0, 0, NB_AUX_B);
+}
+template <int TMt, int TNt>
+__device__ __forceinline__ void tt_mfma_slot(bf16x8* af, bf16x8* bfr, f32x4 (&acc)[TMt][TNt]) {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm reads of the LOAD slot (the compiler does not know they are pending)
+#pragma unroll
+  for (int i = 0; i < TMt; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+  for (int j = 0; j < TNt; ++j) asm volatile("" : "+v"(bfr[j]));
+#pragma unroll
+  for (int i = 0; i < TMt; ++i)
+#pragma unroll
+    for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 #define NB_STAMP(IDX)                                                                                          \
   if ((DIAG & 32) && p.U && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 700))                       \
     ((uint64_t*)p.U)[16000 + (blockIdx.x ? 8 : 0) + (IDX)] = __builtin_readcyclecounter()
@@ -647,6 +700,97 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #undef PP_MFMA
 #undef PP_STEADY
 #undef PP_GENERIC
+  } else if constexpr (NT == 512 && TA && TB && BM == 256 && BN == 256 && STAGES == 4 && !(DIAG & 0x8000)) {
+    // ---- the weight-gradient kernel (both operands token-major): the ping-pong of the generic branch below with the LOAD slot stripped to
+    // its memory instructions, as the k-contiguous branch above (round 4).  The generic branch's LOAD slot carried 41 vector and ~19 scalar
+    // instructions around its 4 LDS-DMA pieces and 24 transposed reads (per-lane DMA offsets re-derived from k0, LDS destinations through
+    // v_readfirstlane, one XOR + add per fragment address on a runtime ring index); every one of them takes a vector-issue slot from the wave
+    // that shares the SIMD and is in its MFMA slot.  Here: wave index in an SGPR (scalar DMA destinations), per-lane DMA source offsets
+    // advanced by ONE v_add each per slot (the K advance must stay in the range-checked per-lane offset: the rows past the last token are
+    // zero-filled by the descriptor, and a scalar offset is not range-checked), fragment addresses = 12 per-lane registers set up once +
+    // immediates (tt_frags; ring image with the stage index below the k-row pair), steady state and tail separate.
+    static_assert(WTM == 128 && WTN == 64, "weight-gradient ping-pong: 2 x 4 waves of 128 x 64");
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int grp = wv >> 2;
+    char* const ldsA = lds;
+    char* const ldsB = lds + STAGES * A_BYTES;
+    uint32_t voA[2], voB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pp = i * NT + tid, krow = pp >> 5, slot = pp & 31;
+      const int mc = slot ^ (2 * (krow & 3) + 8 * ((krow >> 3) & 1));
+      voA[i] = (uint32_t)(((kbeg + krow) * lda_ + m0a + mc * 8) * 2);
+      voB[i] = (uint32_t)(((kbeg + krow) * ldb_ + n0 + mc * 8) * 2);
+    }
+    const uint32_t stepA = (uint32_t)(BK * lda_ * 2), stepB = (uint32_t)(BK * ldb_ * 2);
+    uint32_t faA[TMt], faB[TNt];      // fragment addresses (stage 0, lower half)
+    {
+      const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3;
+      const int f = 2 * q + 8 * (g & 1);
+      const uint32_t rowpart = (uint32_t)((4 * g + (q >> 1)) * (STAGES * 1024) + (q & 1) * 512 + ((pq & 1) ? 8 : 0));
+      const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)ldsA;
+      const uint32_t b0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)ldsB;
+#pragma unroll
+      for (int t = 0; t < TMt; ++t) faA[t] = a0 + rowpart + (uint32_t)((((wm * WTM + t * 16) >> 3) + (pq >> 1)) ^ f) * 16u;
+#pragma unroll
+      for (int t = 0; t < TNt; ++t) faB[t] = b0 + rowpart + (uint32_t)((((wn * WTN + t * 16) >> 3) + (pq >> 1)) ^ f) * 16u;
+    }
+    bf16x8 af[TMt], bfr[TNt];
+#define TT_ISSUE(NB_)                                                          \
+    do {                                                                       \
+      tt_issue<(NB_), STAGES>(rsA, rsB, ldsA, ldsB, voA, voB, wv);             \
+      voA[0] += stepA; voA[1] += stepA; voB[0] += stepB; voB[1] += stepB;      \
+    } while (0)
+#define TT_FRAGS(B_) do { tt_frags<(B_), STAGES, TNt>(faB, bfr); tt_frags<(B_), STAGES, TMt>(faA, af); } while (0)
+#define TT_STEADY(B_)                                      \
+    do {                                                   \
+      TT_ISSUE(((B_) + STAGES - 1) % STAGES);              \
+      TT_FRAGS(B_);                                        \
+      wait_vm<(STAGES - 2) * NDMA>();                      \
+      tt_mfma_slot<TMt, TNt>(af, bfr, acc);                \
+    } while (0)
+#define TT_GENERIC(KT, B_)                                                     \
+    do {                                                                       \
+      if ((KT) + STAGES - 1 < nk) TT_ISSUE(((B_) + STAGES - 1) % STAGES);      \
+      TT_FRAGS(B_);                                                            \
+      const int c_ = (nk - 1 - (KT) < STAGES - 1) ? nk - 1 - (KT) : STAGES - 1; \
+      if (c_ >= 3) wait_vm<2 * NDMA>();                                        \
+      else if (c_ == 2) wait_vm<NDMA>();                                       \
+      else if (c_ == 1) wait_vm<0>();                                          \
+      tt_mfma_slot<TMt, TNt>(af, bfr, acc);                                    \
+    } while (0)
+    static_assert(NDMA == 4, "weight-gradient ping-pong: two LDS-DMA pieces per operand, wave and stage");
+    if (0 < nk) TT_ISSUE(0);
+    if (1 < nk) TT_ISSUE(1);
+    if (STAGES > 3 && 2 < nk) TT_ISSUE(2);
+    {
+      const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
+      if (younger >= 2) wait_vm<2 * NDMA>();
+      else if (younger == 1) wait_vm<NDMA>();
+      else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();                 // stage 0 landed for everyone
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
+    int kt = 0;
+    const int n_steady = nk - (STAGES - 1);
+    for (; kt + STAGES <= n_steady; kt += STAGES) {
+      TT_STEADY(0);
+      TT_STEADY(1);
+      TT_STEADY(2);
+      if constexpr (STAGES > 3) TT_STEADY(3 % STAGES);
+    }
+    for (; kt < nk; kt += STAGES) {
+      TT_GENERIC(kt, 0);
+      if (kt + 1 < nk) TT_GENERIC(kt + 1, 1);
+      if (kt + 2 < nk) TT_GENERIC(kt + 2, 2);
+      if constexpr (STAGES > 3) { if (kt + 3 < nk) TT_GENERIC(kt + 3, 3 % STAGES); }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count
+#undef TT_ISSUE
+#undef TT_FRAGS
+#undef TT_STEADY
+#undef TT_GENERIC
   } else if constexpr (NT == 512) {
     // ---- ping-pong (8 waves = 2 groups of one wave per SIMD): a group alternates a LOAD slot (fragment
     // reads of stage j, LDS-DMA of stage j+STAGES-1, counted vmcnt) with an MFMA slot (stage j); group 1

@@ -24,6 +24,10 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--only", default="")
     ap.add_argument("--no_pack", action="store_true")
+    ap.add_argument("--prep", default="none", choices=["none", "copy", "read"],
+                    help="before EVERY timed launch (outside the timed events): copy = rewrite the activation operand with plain stores (an operand the "
+                         "previous kernel has just written, as in the step); read = read it once (sum); none = as is (with --inner 1: last touched a "
+                         "round ago)")
     a = ap.parse_args()
     M, H, F = a.M, a.H, a.F
     dev, bf = "cuda", torch.bfloat16
@@ -62,6 +66,17 @@ def main():
         ("wgrd attn-out  768x768", 2.0 * M * H * H, lambda: E.gemm(dRd, ctx, H, H, M, 1, 1, E.EPI_F32_SPLITK, out=g32["o"])),
         ("wgrd qkv       2304x768", 2.0 * M * 3 * H * H, lambda: E.gemm(dqkv, x, 3 * H, H, M, 1, 1, E.EPI_F32_SPLITK, out=g32["qkv"])),
     ]
+    act = {"fwd  qkv": x, "fwd  attn-out": ctx, "fwd  ffn-up": x1, "fwd  ffn-down": hact, "dgrd ffn-down": dRd, "dgrd ffn-up": dBig,
+           "dgrd attn-out": dRd, "dgrd qkv": dqkv, "wgrd ffn-down": dRd, "wgrd ffn-up": dBig, "wgrd attn-out": dRd, "wgrd qkv": dqkv}
+    spare = {id(t): t.clone() for t in act.values()}
+    sink = torch.zeros(1, device=dev)
+
+    def prep(name):
+        t = next(v for k, v in act.items() if name.startswith(k))
+        if a.prep == "copy":
+            t.copy_(spare[id(t)])
+        elif a.prep == "read":
+            sink.add_(t.view(torch.int16)[::1].sum().float() * 0)
     if a.only:
         jobs = [j for j in jobs if a.only in j[0]]
     for _, _, f in jobs:          # warm-up (workspace allocation, code load)
@@ -69,8 +84,10 @@ def main():
     torch.cuda.synchronize()
     times = [[] for _ in jobs]
     for _ in range(a.rounds):
-        for k, (_, _, f) in enumerate(jobs):
+        for k, (nm_, _, f) in enumerate(jobs):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if a.prep != "none":
+                prep(nm_)
             e0.record()
             for _ in range(a.inner):
                 f()
@@ -78,7 +95,7 @@ def main():
             times[k].append((e0, e1))
     torch.cuda.synchronize()
     tot = 0.0
-    print("# %s  M=%d  lib=%s  NBEST_TILE=%s NBEST_GEMM=%s" % (a.tag, M, os.path.basename(hb.LIB_PATH), os.environ.get("NBEST_TILE", "-"),
+    print("# %s  prep=%s inner=%d  M=%d  lib=%s  NBEST_TILE=%s NBEST_GEMM=%s" % (a.tag, a.prep, a.inner, M, os.path.basename(hb.LIB_PATH), os.environ.get("NBEST_TILE", "-"),
                                                              os.environ.get("NBEST_GEMM", "-")))
     for (name, fl, _), ts in zip(jobs, times):
         v = sorted(e0.elapsed_time(e1) / a.inner * 1e3 for e0, e1 in ts)
