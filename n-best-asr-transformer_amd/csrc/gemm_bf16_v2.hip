@@ -283,24 +283,24 @@ __device__ __forceinline__ void tt_issue(__amdgpu_buffer_rsrc_t rsA, __amdgpu_bu
   for (int i = 0; i < 2; ++i)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(ldsB + ((i * 8 + wv) * STAGES + NB_) * 1024), 16, voB[i], 0, 0, NB_AUX_B);
 }
+// end of a LOAD slot: the (asm) fragment reads have landed; every fragment is redefined AFTER the wait so that no MFMA can be scheduled above it
 template <int TMt, int TNt>
-__device__ __forceinline__ void tt_mfma_slot(bf16x8* af, bf16x8* bfr, f32x4 (&acc)[TMt][TNt]) {
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm reads of the LOAD slot (the compiler does not know they are pending)
+__device__ __forceinline__ void tt_frags_ready(bf16x8* af, bf16x8* bfr) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int i = 0; i < TMt; ++i) asm volatile("" : "+v"(af[i]));
 #pragma unroll
   for (int j = 0; j < TNt; ++j) asm volatile("" : "+v"(bfr[j]));
+}
+template <int TMt, int TNt>
+__device__ __forceinline__ void tt_mfma(const bf16x8* af, const bf16x8* bfr, f32x4 (&acc)[TMt][TNt]) {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int i = 0; i < TMt; ++i)
 #pragma unroll
     for (int j = 0; j < TNt; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
   __builtin_amdgcn_s_setprio(0);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -701,14 +701,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #undef PP_STEADY
 #undef PP_GENERIC
   } else if constexpr (NT == 512 && TA && TB && BM == 256 && BN == 256 && STAGES == 4 && !(DIAG & 0x8000)) {
-    // ---- the weight-gradient kernel (both operands token-major): the ping-pong of the generic branch below with the LOAD slot stripped to
-    // its memory instructions, as the k-contiguous branch above (round 4).  The generic branch's LOAD slot carried 41 vector and ~19 scalar
-    // instructions around its 4 LDS-DMA pieces and 24 transposed reads (per-lane DMA offsets re-derived from k0, LDS destinations through
-    // v_readfirstlane, one XOR + add per fragment address on a runtime ring index); every one of them takes a vector-issue slot from the wave
-    // that shares the SIMD and is in its MFMA slot.  Here: wave index in an SGPR (scalar DMA destinations), per-lane DMA source offsets
-    // advanced by ONE v_add each per slot (the K advance must stay in the range-checked per-lane offset: the rows past the last token are
-    // zero-filled by the descriptor, and a scalar offset is not range-checked), fragment addresses = 12 per-lane registers set up once +
-    // immediates (tt_frags; ring image with the stage index below the k-row pair), steady state and tail separate.
+    // ---- the weight-gradient kernel (both operands token-major), round 4.  Two changes against the generic ping-pong branch below:
+    // (1) the LOAD slot is stripped to its memory instructions, as in the k-contiguous branch above.  The generic LOAD slot carried 41 vector
+    //     and ~19 scalar instructions around its 4 LDS-DMA pieces and 24 transposed reads (per-lane DMA offsets re-derived from k0, LDS
+    //     destinations through v_readfirstlane, one XOR + add per fragment address on a runtime ring index); every one of them takes a
+    //     vector-issue slot from the wave that shares the SIMD and is in its MFMA slot.  Here: wave index in an SGPR (scalar DMA
+    //     destinations), per-lane DMA source offsets advanced by ONE v_add each per slot (the K advance must stay in the range-checked
+    //     per-lane offset: the rows past the last token are zero-filled by the descriptor, and a scalar offset is not range-checked),
+    //     fragment addresses = 12 per-lane registers set up once + immediates (tt_frags; ring image with the stage index below the
+    //     k-row pair), steady state and tail separate.  165 -> 136 us per launch.
+    // (2) ONE workgroup barrier per stage instead of two per slot.  Stamps (tools/slot_trace_tt.py) showed LOAD slot 620 and MFMA slot 655
+    //     cycles plus 80 - 120 cycles at EACH of the two barriers of a slot - 80 is what s_barrier costs the LAST wave to arrive.  The two
+    //     groups need one rendezvous per stage, not four: group 0 runs [LOAD k | MFMA k], group 1 [MFMA k-1 | LOAD k] between two
+    //     barriers - each group's LOAD overlaps the other's MFMA by construction, and the barrier at the end of the period is what orders
+    //     the ring: every wave has retired its own LDS-DMA share of stage k+1 (counted vmcnt) and its fragment reads of stage k
+    //     (lgkmcnt(0) at the END of the LOAD slot) before it, and stage k+1 is read / ring slot k-1 is overwritten only after it.
+    //     Measured: NO gain (136 us either way) - kept because it is the simpler contract (one rendezvous, every wait before it).
+    // Measured and rejected on this loop (same call, A/B, layer shapes): a fifth ring stage (+0 ... +3 %); two or all four LDS-DMA pieces of a
+    // stage issued between the MFMA groups instead of in the LOAD slot (+-0, +2 %); half of the fragment reads issued between the MFMA groups
+    // ("rolling" A rows on a five-slot ring, lgkmcnt waits inside the MFMA slot: +10 %).  The stamps leave LOAD 620 + MFMA 655 cycles per wave
+    // and stage against 2 x 512 MFMA-pipe cycles per SIMD: 68 % is the ceiling of this two-slot form, 56 % is measured.
     static_assert(WTM == 128 && WTN == 64, "weight-gradient ping-pong: 2 x 4 waves of 128 x 64");
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int grp = wv >> 2;
@@ -736,33 +748,45 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       for (int t = 0; t < TNt; ++t) faB[t] = b0 + rowpart + (uint32_t)((((wn * WTN + t * 16) >> 3) + (pq >> 1)) ^ f) * 16u;
     }
     bf16x8 af[TMt], bfr[TNt];
+    static_assert(NDMA == 4, "weight-gradient ping-pong: two LDS-DMA pieces per operand, wave and stage");
 #define TT_ISSUE(NB_)                                                          \
     do {                                                                       \
       tt_issue<(NB_), STAGES>(rsA, rsB, ldsA, ldsB, voA, voB, wv);             \
       voA[0] += stepA; voA[1] += stepA; voB[0] += stepB; voB[1] += stepB;      \
     } while (0)
 #define TT_FRAGS(B_) do { tt_frags<(B_), STAGES, TNt>(faB, bfr); tt_frags<(B_), STAGES, TMt>(faA, af); } while (0)
-#define TT_STEADY(B_)                                      \
+    // LOAD slot of stage kt (ring slot B_): issue stage kt + STAGES - 1 into ring slot B_ - 1, read the fragments of stage kt, retire this
+    // wave's share of stage kt + 1 (the STAGES - 2 younger stages stay in flight) and the fragment reads
+#define TT_LOAD_STEADY(B_)                                 \
     do {                                                   \
       TT_ISSUE(((B_) + STAGES - 1) % STAGES);              \
       TT_FRAGS(B_);                                        \
       wait_vm<(STAGES - 2) * NDMA>();                      \
-      tt_mfma_slot<TMt, TNt>(af, bfr, acc);                \
+      tt_frags_ready<TMt, TNt>(af, bfr);                   \
     } while (0)
-#define TT_GENERIC(KT, B_)                                                     \
+#define TT_LOAD_GENERIC(KT, B_)                                                \
     do {                                                                       \
-      if ((KT) + STAGES - 1 < nk) TT_ISSUE(((B_) + STAGES - 1) % STAGES);      \
+      const bool is_ = (KT) + STAGES - 1 < nk;                                 \
+      if (is_) TT_ISSUE(((B_) + STAGES - 1) % STAGES);                         \
       TT_FRAGS(B_);                                                            \
-      const int c_ = (nk - 1 - (KT) < STAGES - 1) ? nk - 1 - (KT) : STAGES - 1; \
-      if (c_ >= 3) wait_vm<2 * NDMA>();                                        \
-      else if (c_ == 2) wait_vm<NDMA>();                                       \
-      else if (c_ == 1) wait_vm<0>();                                          \
-      tt_mfma_slot<TMt, TNt>(af, bfr, acc);                                    \
+      if ((KT) + 1 < nk) {                                                     \
+        int full_ = nk - 2 - (KT);                                             \
+        full_ = full_ < 0 ? 0 : (full_ > STAGES - 3 ? STAGES - 3 : full_);     \
+        wait_vm_even(NDMA * full_ + (is_ ? NDMA : 0));                         \
+      }                                                                        \
+      tt_frags_ready<TMt, TNt>(af, bfr);                                       \
     } while (0)
-    static_assert(NDMA == 4, "weight-gradient ping-pong: two LDS-DMA pieces per operand, wave and stage");
+#define TT_MFMA() tt_mfma<TMt, TNt>(af, bfr, acc)
+    // (DIAG & 32: s_memtime stamps of workgroup 0, one wave per group: period start, between its two halves, before and after the barrier -
+    // tools/slot_trace_tt.py)
+    uint64_t* const stamps = ((DIAG & 32) && p.U && blockIdx.x == 0 && lane == 0 && (wv & 3) == 0) ? (uint64_t*)p.U + (wv >> 2) * 8192 : nullptr;
+    int sp = 0;
+#define TT_ST(I) do { if ((DIAG & 32) && stamps) stamps[4 * sp + (I)] = __builtin_readcyclecounter(); } while (0)
+#define TT_MID() TT_ST(1)
+#define TT_BAR() do { __builtin_amdgcn_sched_barrier(0); TT_ST(2); __builtin_amdgcn_s_barrier(); TT_ST(3); ++sp; TT_ST(0); __builtin_amdgcn_sched_barrier(0); } while (0)
     if (0 < nk) TT_ISSUE(0);
     if (1 < nk) TT_ISSUE(1);
-    if (STAGES > 3 && 2 < nk) TT_ISSUE(2);
+    if (2 < nk) TT_ISSUE(2);
     {
       const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
       if (younger >= 2) wait_vm<2 * NDMA>();
@@ -771,26 +795,52 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }
     __builtin_amdgcn_s_barrier();                 // stage 0 landed for everyone
     asm volatile("" ::: "memory");
-    if (grp == 1) __builtin_amdgcn_s_barrier();   // offset group 1 by one slot
-    int kt = 0;
-    const int n_steady = nk - (STAGES - 1);
-    for (; kt + STAGES <= n_steady; kt += STAGES) {
-      TT_STEADY(0);
-      TT_STEADY(1);
-      TT_STEADY(2);
-      if constexpr (STAGES > 3) TT_STEADY(3 % STAGES);
+    TT_ST(0);
+    const int n_steady = nk - (STAGES - 1);       // stages kt < n_steady still have a stage to issue in their LOAD slot
+    if (grp == 0) {
+      // period kt: LOAD kt | MFMA kt | barrier
+      int kt = 0;
+      for (; kt + STAGES <= n_steady; kt += STAGES) {
+        TT_LOAD_STEADY(0); TT_MID(); TT_MFMA(); TT_BAR();
+        TT_LOAD_STEADY(1); TT_MID(); TT_MFMA(); TT_BAR();
+        TT_LOAD_STEADY(2); TT_MID(); TT_MFMA(); TT_BAR();
+        TT_LOAD_STEADY(3); TT_MID(); TT_MFMA(); TT_BAR();
+      }
+      for (; kt < nk; kt += STAGES) {
+        TT_LOAD_GENERIC(kt, 0); TT_MID(); TT_MFMA(); TT_BAR();
+        if (kt + 1 < nk) { TT_LOAD_GENERIC(kt + 1, 1); TT_MID(); TT_MFMA(); TT_BAR(); }
+        if (kt + 2 < nk) { TT_LOAD_GENERIC(kt + 2, 2); TT_MID(); TT_MFMA(); TT_BAR(); }
+        if (kt + 3 < nk) { TT_LOAD_GENERIC(kt + 3, 3); TT_MID(); TT_MFMA(); TT_BAR(); }
+      }
+      TT_BAR();                                   // the period in which group 1 multiplies its last stage
+    } else {
+      // period 0: LOAD 0 | barrier;  period kt >= 1: MFMA kt-1 | LOAD kt | barrier;  last: MFMA nk-1 | barrier
+      if (0 < nk) TT_LOAD_GENERIC(0, 0);
+      TT_BAR();
+      int kt = 1;
+      for (; kt + STAGES <= n_steady; kt += STAGES) {       // kt = 1 (mod 4): ring slots 1, 2, 3, 0
+        TT_MFMA(); TT_MID(); TT_LOAD_STEADY(1); TT_BAR();
+        TT_MFMA(); TT_MID(); TT_LOAD_STEADY(2); TT_BAR();
+        TT_MFMA(); TT_MID(); TT_LOAD_STEADY(3); TT_BAR();
+        TT_MFMA(); TT_MID(); TT_LOAD_STEADY(0); TT_BAR();
+      }
+      for (; kt < nk; kt += STAGES) {
+        TT_MFMA(); TT_MID(); TT_LOAD_GENERIC(kt, 1); TT_BAR();
+        if (kt + 1 < nk) { TT_MFMA(); TT_MID(); TT_LOAD_GENERIC(kt + 1, 2); TT_BAR(); }
+        if (kt + 2 < nk) { TT_MFMA(); TT_MID(); TT_LOAD_GENERIC(kt + 2, 3); TT_BAR(); }
+        if (kt + 3 < nk) { TT_MFMA(); TT_MID(); TT_LOAD_GENERIC(kt + 3, 0); TT_BAR(); }
+      }
+      if (0 < nk) TT_MFMA();
+      TT_BAR();
     }
-    for (; kt < nk; kt += STAGES) {
-      TT_GENERIC(kt, 0);
-      if (kt + 1 < nk) TT_GENERIC(kt + 1, 1);
-      if (kt + 2 < nk) TT_GENERIC(kt + 2, 2);
-      if constexpr (STAGES > 3) { if (kt + 3 < nk) TT_GENERIC(kt + 3, 3 % STAGES); }
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count
 #undef TT_ISSUE
 #undef TT_FRAGS
-#undef TT_STEADY
-#undef TT_GENERIC
+#undef TT_LOAD_STEADY
+#undef TT_LOAD_GENERIC
+#undef TT_MFMA
+#undef TT_BAR
+#undef TT_MID
+#undef TT_ST
   } else if constexpr (NT == 512) {
     // ---- ping-pong (8 waves = 2 groups of one wave per SIMD): a group alternates a LOAD slot (fragment
     // reads of stage j, LDS-DMA of stage j+STAGES-1, counted vmcnt) with an MFMA slot (stage j); group 1
