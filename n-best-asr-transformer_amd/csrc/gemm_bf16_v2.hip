@@ -57,6 +57,7 @@ struct GemmP2 {
   // nullptr: B is read row by row
   const bf16* Bp;
   uint32_t bp_bytes;
+  int bp_bn;          // tile width B was packed for (nbest_pack_bn): the kernel's BN, or BN / 2 (a 384-column tile reads two 192-column blocks)
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, a_bytes, 0x00020000);
-  const bool b_packed = kDirect && NT == 512 && p.Bp != nullptr;      // workgroup-uniform
+  const bool b_packed = kDirect && NT == 512 && p.Bp != nullptr && (BN != 384 || !(DIAG & 0x8000));      // workgroup-uniform
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(b_packed ? (void*)p.Bp : (void*)opB, 0, b_packed ? p.bp_bytes : b_bytes, 0x00020000);
   const int nkt = (int)(p.K / BK);
 
@@ -622,8 +623,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
       const int pp = i * NT + tid;
-      if (b_packed) voB[i] = (uint32_t)pp * 16u;
-      else {
+      if (b_packed) {
+        // packed image: per (packed tile column, K stage) a block of bp_bn x 32; a tile wider than the packing reads BN / bp_bn blocks of
+        // ADJACENT packed tile columns, nkt stage blocks apart
+        const int per = p.bp_bn * 4;                          // 16-byte chunks per packed stage block
+        const int blk = pp / per;
+        voB[i] = (uint32_t)blk * (uint32_t)nkt * (uint32_t)(per * 16) + (uint32_t)(pp - blk * per) * 16u;
+      } else {
         const int row = pp >> 2, slot = pp & 3, kc = slot ^ ((-(row >> 2)) & 3);
         int grow = row;
         if constexpr (kPW > 0) { const int x = row % kPW; grow = row - x + (kPW / 16) * (x & 15) + (x >> 4); }
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
       if ((BN * 4) % NT != 0 && i == NIB - 1 && (i * NT + wv * 64) * 16 >= BN * 64) { voB[i] = 0xFFFFFFF0u; dumpB = true; }
     }
     const uint32_t sB0 = b_packed ? (uint32_t)(tile_n * nkt) * (uint32_t)B_BYTES : (uint32_t)(kbeg * 2);
-    const uint32_t sBstep = b_packed ? (uint32_t)B_BYTES : (uint32_t)(BK * 2);
+    const uint32_t sBstep = b_packed ? (uint32_t)(p.bp_bn * BK * 2) : (uint32_t)(BK * 2);
     char* const dump = lds + STAGES * STAGE + (wv % (NT / 64)) * 1024;
     // (device function templates, not lambdas: the HOST pass of hipcc silently drops the kernel stub of every instantiation whose body
     // calls a generic lambda that issues LDS-DMA builtins - the library then fails to load with an undefined kernel symbol)
@@ -1630,6 +1636,7 @@ static int forced_tile() {
     if (!strcmp(e, "128x256")) return 4;
     if (!strcmp(e, "256x128")) return 2;
     if (!strcmp(e, "128x128")) return 1;
+    if (!strcmp(e, "128x384")) return 6;
     return 0;
   }();
   return v;
@@ -1647,7 +1654,8 @@ static Plan make_plan(const nbest_gemm_args* a) {
   // 256x128 where it fills the chip (two workgroups per CU -> 512 slots) and is not a weight gradient
   const int64_t t256 = ((a->M + 255) / 256) * (a->N / 128);
   pl.bm = (!a->trans_a && t256 >= 1024) ? 256 : 128;
-  const int ft = forced_tile();
+  const int ft6 = forced_tile();
+  const int ft = (ft6 == 6) ? 0 : ft6;      // 128x384 is an ADDITIONAL choice for the N = 768 shapes: every other shape plans as usual
   const bool ok256 = (a->N % 256 == 0) && (!a->trans_a || a->M % 256 == 0);
   if (ft == 3 && ok256) { pl.bm = 256; pl.bn = 256; }
   else if (ft == 4 && ok256) { pl.bm = 128; pl.bn = 256; }
@@ -1686,6 +1694,11 @@ static Plan make_plan(const nbest_gemm_args* a) {
 #endif
       if (ft == 5 || (t192 >= t192_min && 0.85 * eff(t192) > ecur)) { pl.bm = 256; pl.bn = 192; }
     }
+    // 128 x 384 tiles (2 x 4 waves of 64 x 96; round 4): the same MFMA work per stage as 256 x 192 with HALF the bytes of the A operand - the
+    // activation panel, which in the training step comes cold from HBM - and twice those of the weight panel, which the L2
+    // holds (and which arrives packed: two adjacent 192-column blocks).  Takes over wherever 256 x 192 was chosen and N is a multiple of
+    // 384.  Same call, alternating: the five N = 768 GEMMs of a layer 620 -> 586 us cold / 541 -> 510 warm; the step 21.15 / 21.22 -> 20.85 / 20.88 ms.
+    if (pl.bm == 256 && pl.bn == 192 && a->N % 384 == 0 && a->K % BK == 0 && ft != 5) { pl.bm = 128; pl.bn = 384; }
   }
   const int64_t tiles = ((a->M + pl.bm - 1) / pl.bm) * (a->N / pl.bn);
   const int64_t slots = (pl.bn >= 192) ? 256 : 512;   // workgroups resident at once
@@ -1750,7 +1763,10 @@ static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
 
 // v2 is only faster with its 256x128 tile (measured: +8..14 % on the wide-N forward / dgrad GEMMs); the
 // 128x128 BK=32 ring loses to v1's 128x128 BK=64 (half the MFMAs per barrier and per DMA instruction)
-bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a) { return make_plan(a).bm == 256 || forced_tile() != 0; }   // 256x128 ring or 256x256 ping-pong
+bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a) {
+  const Plan pl = make_plan(a);
+  return pl.bm == 256 || (pl.bm == 128 && pl.bn == 384) || (forced_tile() != 0 && forced_tile() != 6);
+}   // 256x128 ring or 256x256 ping-pong
 
 int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
 
@@ -1786,11 +1802,13 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
   p.slab = (float*)a->ws;
   p.colpart = nullptr;
   p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.m_split = 0; p.a2_bytes = p.b2_bytes = 0;
-  p.Bp = nullptr; p.bp_bytes = 0;
-  if (a->B_packed && a->b_pack_bn == pl.bn && pl.bm == 256 && (pl.bn == 256 || pl.bn == 192) && !a->trans_a && !a->trans_b &&
+  p.Bp = nullptr; p.bp_bytes = 0; p.bp_bn = 0;
+  if (a->B_packed && ((a->b_pack_bn == pl.bn && pl.bm == 256 && (pl.bn == 256 || pl.bn == 192)) || (pl.bm == 128 && pl.bn == 384 && a->b_pack_bn == 192)) &&
+      !a->trans_a && !a->trans_b &&
       a->epilogue != NBEST_EPI_F32_SPLITK && a->K % BK == 0 && a->N * a->K * 2 < ((int64_t)1 << 32) && ((uintptr_t)a->B_packed & 15) == 0) {
     p.Bp = (const bf16*)a->B_packed;
     p.bp_bytes = (uint32_t)(a->N * a->K * 2);
+    p.bp_bn = a->b_pack_bn;
   }
   if (a->colsum_out && a->epilogue != NBEST_EPI_F32_SPLITK) {
     NB_CHECK(a->ws && a->ws_bytes >= nbest_gemm_bf16_v2_ws_bytes(a), NBEST_ERR_WORKSPACE, "gemm: column-sum workspace too small");
@@ -1840,7 +1858,10 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
   const int grid = p.tiles_m * p.tiles_n * p.splits;
   int rc, wave_rows = 2;   // wave rows per tile = partial rows of the fused column sums
   NB_CHECK(a->N % pl.bn == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld is not a multiple of the %d-column tile", (long long)a->N, pl.bn);
-  if (pl.bm == 256 && pl.bn == 192) {
+  if (pl.bm == 128 && pl.bn == 384) {
+    if (a->K >= 2048 || stages5_enabled()) rc = launch2<128, 384, 2, 4, 5, false, false>(p, epi, grid, st);
+    else rc = launch2<128, 384, 2, 4, 4, false, false>(p, epi, grid, st);
+  } else if (pl.bm == 256 && pl.bn == 192) {
     // ring depth: the operand delivery of these kernels is bound by bytes in flight against the LDS-DMA latency (3 stages of 28-32 KB
     // against ~2 us); a fifth stage (all 160 KB of LDS at 256 x 256) pays at long K - FFN-down forward 162 -> 155 us, FFN-up dgrad 157 ->
     // 154, QKV dgrad 122 -> 120 - and costs 1-2 % at K = 768, where the longer prologue of each tile weighs more (same-call A/B, twice)
