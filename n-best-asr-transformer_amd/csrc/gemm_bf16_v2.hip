@@ -1053,7 +1053,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     for (int j = 0; j < TNt; ++j) colacc[j] = 0.f;
     const uint32_t voC = (uint32_t)((drow0 * p.ldc + dcol) * 2), svC = (uint32_t)(2 * p.ldc);
     const uint32_t dbase0 = (uint32_t)(drow0 * p.N + dcol), sD = (uint32_t)p.N;
-    const bool want_cols = p.colpart != nullptr;
+    // fused column sums: compiled into the x GELU' epilogue only (the FFN-up bias gradient - the one caller in the training step).  As a
+    // run-time option of EVERY epilogue it cost each of them a select + an add per element (the compiler if-converts the guarded
+    // accumulate): 256 of the 676 vector instructions of the plain-bias epilogue.  Other epilogues with colsum_out: nbest_gemm_bf16_v2_wins.
+    constexpr bool kCols = (EPI == NBEST_EPI_DGELU);
+    const bool want_cols = kCols && p.colpart != nullptr;
 #pragma unroll
     for (int i = 0; i < TMt; ++i) {
 #pragma unroll
@@ -1110,14 +1114,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
           for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsC, voC + rr * svC, 0, 2);
         }
-        if (want_cols) {
-          const bool live = (drow0 + rr) < p.M;
+        if constexpr (kCols) {
+          const bool live = want_cols && (drow0 + rr) < p.M;
 #pragma unroll
           for (int j = 0; j < TNt; ++j) colacc[j] += live ? v[j] : 0.f;
         }
       }
     }
-    if (want_cols) {   // fused bias gradient: sum over the 4 lane groups (rows 4g + e) -> one partial row per wave
+    if (kCols && want_cols) {   // fused bias gradient: sum over the 4 lane groups (rows 4g + e) -> one partial row per wave
 #pragma unroll
       for (int j = 0; j < TNt; ++j) {
         float x = colacc[j];
@@ -1764,6 +1768,8 @@ static int launch2(const GemmP2& p, int epi, int grid, hipStream_t st) {
 // v2 is only faster with its 256x128 tile (measured: +8..14 % on the wide-N forward / dgrad GEMMs); the
 // 128x128 BK=32 ring loses to v1's 128x128 BK=64 (half the MFMAs per barrier and per DMA instruction)
 bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a) {
+  // column sums fused into an epilogue other than x GELU': the generation-1 kernel carries them for every epilogue (no caller in the training step)
+  if (a->colsum_out && a->epilogue != NBEST_EPI_DGELU && a->epilogue != NBEST_EPI_F32_SPLITK && !a->trans_a && !a->trans_b) return false;
   const Plan pl = make_plan(a);
   return pl.bm == 256 || (pl.bm == 128 && pl.bn == 384) || (forced_tile() != 0 && forced_tile() != 6);
 }   // 256x128 ring or 256x256 ping-pong
@@ -1811,6 +1817,8 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
     p.bp_bn = a->b_pack_bn;
   }
   if (a->colsum_out && a->epilogue != NBEST_EPI_F32_SPLITK) {
+    NB_CHECK(a->epilogue == NBEST_EPI_DGELU || a->trans_a || a->trans_b, NBEST_ERR_ARG,
+             "gemm(bf16, generation 2): column sums are fused into the x GELU' epilogue only (nbest_gemm routes the others to generation 1)");
     NB_CHECK(a->ws && a->ws_bytes >= nbest_gemm_bf16_v2_ws_bytes(a), NBEST_ERR_WORKSPACE, "gemm: column-sum workspace too small");
     p.colpart = (float*)a->ws;
   }
