@@ -559,6 +559,26 @@ __device__ __forceinline__ i32x8 read_frag8t(const char* tile, int f0, int lane)
   return out;
 }
 
+// fragment reads of the stripped loop: one per-lane address register per 32-feature fragment + immediates (ring slot B_: + B_ KiB; read q:
+// 8 token rows = two row groups further)
+template <int OFF> __device__ __forceinline__ i32x2 ds_read_tr8_off(uint32_t a) {
+  i32x2 v;
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+template <int B_, int STAGES, int NF>
+__device__ __forceinline__ void tt8_frags(const uint32_t* base, i32x8* fr) {
+  constexpr int Q = 2 * STAGES * 1024;
+#pragma unroll
+  for (int t = 0; t < NF; ++t) {
+    const i32x2 v0 = ds_read_tr8_off<B_ * 1024>(base[t]);
+    const i32x2 v1 = ds_read_tr8_off<B_ * 1024 + Q>(base[t]);
+    const i32x2 v2 = ds_read_tr8_off<B_ * 1024 + 2 * Q>(base[t]);
+    const i32x2 v3 = ds_read_tr8_off<B_ * 1024 + 3 * Q>(base[t]);
+    fr[t] = i32x8{v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
+  }
+}
+
 __global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int BM = 256, BN = 256, WN = 4, STAGES = 4;
@@ -592,65 +612,139 @@ __global__ __launch_bounds__(512, 2) void gemm8tt_kernel(GemmP8T p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int grp = __builtin_amdgcn_readfirstlane(wm);
+  // ---- main loop: the weight-gradient ping-pong of gemm_bf16_v2.hip (round 4), byte for byte in structure: LOAD slot stripped to its
+  // memory instructions (wave index in an SGPR -> scalar LDS-DMA destinations; per-lane source offsets advanced by one v_add per piece
+  // and slot - the token advance stays in the range-checked per-lane offset; 6 fragment-address registers set up once + immediates on a
+  // ring image [16 groups of 4 token rows][stage][4 rows x 256 B] per operand), ONE workgroup barrier per stage (group 0: LOAD k | MFMA k,
+  // group 1: MFMA k-1 | LOAD k), every counted wait before the barrier.  The generic loop it replaces re-derived the DMA offsets and the
+  // 24 fragment addresses in every slot (stage_tile8t / read_frag8t on a runtime ring index).
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int grp = wv >> 2;             // = wm
+  char* const ldsA = lds;
+  char* const ldsB = lds + STAGES * A_BYTES;
+  uint32_t voA[2], voB[2];
 #pragma unroll
-  for (int s0 = 0; s0 < STAGES - 1; ++s0) {
-    if (s0 < nk) {
-      stage_tile8t(rsA, lds + s0 * STAGE, m0a, kbeg + (int64_t)s0 * BK8, lda_, tid);
-      stage_tile8t(rsB, lds + s0 * STAGE + A_BYTES, n0, kbeg + (int64_t)s0 * BK8, ldb_, tid);
+  for (int i = 0; i < 2; ++i) {
+    const int pp = i * 512 + tid, row = pp >> 4, slot = pp & 15;
+    const int t = slot ^ (row & 7);
+    const int c = ((t & 7) << 1) | (t >> 3);
+    voA[i] = (uint32_t)((kbeg + row) * lda_ + m0a + c * 16);
+    voB[i] = (uint32_t)((kbeg + row) * ldb_ + n0 + c * 16);
+  }
+  const uint32_t stepA = (uint32_t)(BK8 * lda_), stepB = (uint32_t)(BK8 * ldb_);
+  uint32_t faA[TMb], faB[TNb];
+  {
+    const int G = lane >> 4, i16 = lane & 15, j8 = i16 >> 1, pp = i16 & 1;
+    const int row0 = 32 * (G >> 1) + j8;                          // token row of read q = 0 (q adds 8 rows = two row groups)
+    const uint32_t rowpart = (uint32_t)((row0 >> 2) * (STAGES * 1024) + (row0 & 3) * 256 + 8 * pp);
+    const uint32_t a0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)ldsA;
+    const uint32_t b0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)ldsB;
+#pragma unroll
+    for (int t = 0; t < TMb; ++t) {
+      const int chunk = ((wm * WTM + t * 32) >> 4) + (G & 1);
+      faA[t] = a0 + rowpart + (uint32_t)(((((chunk & 1) << 3) | (chunk >> 1)) ^ (row0 & 7)) << 4);
+    }
+#pragma unroll
+    for (int t = 0; t < TNb; ++t) {
+      const int chunk = ((wn * WTN + t * 32) >> 4) + (G & 1);
+      faB[t] = b0 + rowpart + (uint32_t)(((((chunk & 1) << 3) | (chunk >> 1)) ^ (row0 & 7)) << 4);
     }
   }
+  i32x8 af[TMb], bfr[TNb];
+#define T8_ISSUE(NB_)                                                                                                                    \
+  do {                                                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(ldsA + ((i * 8 + wv) * STAGES + (NB_)) * 1024), 16, voA[i], 0, 0, 0);        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                                        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(ldsB + ((i * 8 + wv) * STAGES + (NB_)) * 1024), 16, voB[i], 0, 0, 0);        \
+    voA[0] += stepA; voA[1] += stepA; voB[0] += stepB; voB[1] += stepB;                                                                  \
+  } while (0)
+#define T8_FRAGS(B_) do { tt8_frags<(B_), STAGES, TNb>(faB, bfr); tt8_frags<(B_), STAGES, TMb>(faA, af); } while (0)
+#define T8_READY()                                                                     \
+  do {                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+    _Pragma("unroll") for (int i = 0; i < TMb; ++i) asm volatile("" : "+v"(af[i]));    \
+    _Pragma("unroll") for (int j = 0; j < TNb; ++j) asm volatile("" : "+v"(bfr[j]));   \
+  } while (0)
+#define T8_LOAD_STEADY(B_) do { T8_ISSUE(((B_) + STAGES - 1) % STAGES); T8_FRAGS(B_); wait_vm8<(STAGES - 2) * NDMA>(); T8_READY(); } while (0)
+#define T8_LOAD_GENERIC(KT, B_)                                                \
+  do {                                                                         \
+    const bool is_ = (KT) + STAGES - 1 < nk;                                   \
+    if (is_) T8_ISSUE(((B_) + STAGES - 1) % STAGES);                           \
+    T8_FRAGS(B_);                                                              \
+    if ((KT) + 1 < nk) {                                                       \
+      int full_ = nk - 2 - (KT);                                               \
+      full_ = full_ < 0 ? 0 : (full_ > STAGES - 3 ? STAGES - 3 : full_);       \
+      const int cnt_ = NDMA * full_ + (is_ ? NDMA : 0);                        \
+      if (cnt_ >= 8) wait_vm8<8>(); else if (cnt_ == 4) wait_vm8<4>(); else wait_vm8<0>(); \
+    }                                                                          \
+    T8_READY();                                                                \
+  } while (0)
+#define T8_MFMA()                                                                                                          \
+  do {                                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < TMb; ++i)                                                                        \
+      _Pragma("unroll") for (int j = 0; j < TNb; ++j)                                                                      \
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 127, 0, 127);       \
+    __builtin_amdgcn_s_setprio(0);                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+  } while (0)
+#define T8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  static_assert(STAGES == 4 && NDMA == 4, "gemm8tt ping-pong: four ring slots, two LDS-DMA pieces per operand, wave and stage");
+  if (0 < nk) T8_ISSUE(0);
+  if (1 < nk) T8_ISSUE(1);
+  if (2 < nk) T8_ISSUE(2);
   {
     const int younger = (nk - 1 < STAGES - 2) ? nk - 1 : STAGES - 2;
     if (younger >= 2) wait_vm8<2 * NDMA>();
     else if (younger == 1) wait_vm8<NDMA>();
     else wait_vm8<0>();
   }
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();                 // stage 0 landed for everyone
   asm volatile("" ::: "memory");
-  if (grp == 1) __builtin_amdgcn_s_barrier();
-  int buf = 0;
-  i32x8 af[TMb], bfr[TNb];
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + STAGES - 1 < nk) {
-      int nb = buf + STAGES - 1;
-      if (nb >= STAGES) nb -= STAGES;
-      const int64_t k0 = kbeg + (int64_t)(kt + STAGES - 1) * BK8;
-      stage_tile8t(rsA, lds + nb * STAGE, m0a, k0, lda_, tid);
-      stage_tile8t(rsB, lds + nb * STAGE + A_BYTES, n0, k0, ldb_, tid);
+  const int n_steady = nk - (STAGES - 1);
+  if (grp == 0) {
+    int kt = 0;
+    for (; kt + STAGES <= n_steady; kt += STAGES) {
+      T8_LOAD_STEADY(0); T8_MFMA(); T8_BAR();
+      T8_LOAD_STEADY(1); T8_MFMA(); T8_BAR();
+      T8_LOAD_STEADY(2); T8_MFMA(); T8_BAR();
+      T8_LOAD_STEADY(3); T8_MFMA(); T8_BAR();
     }
-    const char* cur = lds + buf * STAGE;
-#pragma unroll
-    for (int j = 0; j < TNb; ++j) bfr[j] = read_frag8t(cur + A_BYTES, wn * WTN + j * 32, lane);
-#pragma unroll
-    for (int i = 0; i < TMb; ++i) af[i] = read_frag8t(cur, wm * WTM + i * 32, lane);
-    {
-      const int c = (nk - 1 - kt < STAGES - 1) ? nk - 1 - kt : STAGES - 1;
-      if (c >= 3) wait_vm8<2 * NDMA>();
-      else if (c == 2) wait_vm8<NDMA>();
-      else if (c == 1) wait_vm8<0>();
+    for (; kt < nk; kt += STAGES) {
+      T8_LOAD_GENERIC(kt, 0); T8_MFMA(); T8_BAR();
+      if (kt + 1 < nk) { T8_LOAD_GENERIC(kt + 1, 1); T8_MFMA(); T8_BAR(); }
+      if (kt + 2 < nk) { T8_LOAD_GENERIC(kt + 2, 2); T8_MFMA(); T8_BAR(); }
+      if (kt + 3 < nk) { T8_LOAD_GENERIC(kt + 3, 3); T8_MFMA(); T8_BAR(); }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm reads are invisible to the compiler's wait-count pass
-#pragma unroll
-    for (int i = 0; i < TMb; ++i) asm volatile("" : "+v"(af[i]));
-#pragma unroll
-    for (int j = 0; j < TNb; ++j) asm volatile("" : "+v"(bfr[j]));
-#pragma unroll
-    for (int i = 0; i < TMb; ++i)
-#pragma unroll
-      for (int j = 0; j < TNb; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 127, 0, 127);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+    T8_BAR();
+  } else {
+    if (0 < nk) T8_LOAD_GENERIC(0, 0);
+    T8_BAR();
+    int kt = 1;
+    for (; kt + STAGES <= n_steady; kt += STAGES) {
+      T8_MFMA(); T8_LOAD_STEADY(1); T8_BAR();
+      T8_MFMA(); T8_LOAD_STEADY(2); T8_BAR();
+      T8_MFMA(); T8_LOAD_STEADY(3); T8_BAR();
+      T8_MFMA(); T8_LOAD_STEADY(0); T8_BAR();
+    }
+    for (; kt < nk; kt += STAGES) {
+      T8_MFMA(); T8_LOAD_GENERIC(kt, 1); T8_BAR();
+      if (kt + 1 < nk) { T8_MFMA(); T8_LOAD_GENERIC(kt + 1, 2); T8_BAR(); }
+      if (kt + 2 < nk) { T8_MFMA(); T8_LOAD_GENERIC(kt + 2, 3); T8_BAR(); }
+      if (kt + 3 < nk) { T8_MFMA(); T8_LOAD_GENERIC(kt + 3, 0); T8_BAR(); }
+    }
+    if (0 < nk) T8_MFMA();
+    T8_BAR();
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef T8_ISSUE
+#undef T8_FRAGS
+#undef T8_READY
+#undef T8_LOAD_STEADY
+#undef T8_LOAD_GENERIC
+#undef T8_MFMA
+#undef T8_BAR
 
   float* ep = (float*)lds + wave * 2048;
   __builtin_amdgcn_s_barrier();
