@@ -1696,7 +1696,11 @@ static Plan make_plan(const nbest_gemm_args* a) {
 #ifdef NBEST_EXPERIMENTS
       if (const char* e = getenv("NBEST_T192MIN")) t192_min = atoll(e);
 #endif
-      if (ft == 5 || (t192 >= t192_min && 0.85 * eff(t192) > ecur)) { pl.bm = 256; pl.bn = 192; }
+      double handicap = 0.85;
+#ifdef NBEST_EXPERIMENTS
+      if (const char* e = getenv("NBEST_T192H")) handicap = atof(e);
+#endif
+      if (ft == 5 || (t192 >= t192_min && handicap * eff(t192) > ecur)) { pl.bm = 256; pl.bn = 192; }
     }
     // 128 x 384 tiles (2 x 4 waves of 64 x 96; round 4): the same MFMA work per stage as 256 x 192 with HALF the bytes of the A operand - the
     // activation panel, which in the training step comes cold from HBM - and twice those of the weight panel, which the L2
@@ -1852,6 +1856,14 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
   // Cache.  Same-box sweep of the five N = 768 launches of a layer: 606 / 584 / 578 us with 1 / 2 / 4 tile columns per group - one
   // column per group loses 4 %, two (the rule's choice at K >= 2304) and row-major tie.)
   p.gn = (!a->trans_a && !a->trans_b) ? nb_group_cols(a->N / pl.bn, (int64_t)pl.bn * a->K * 2, 2400) : (int)(a->N / pl.bn);
+  // 128 x 384 tiles: the two tile columns of an M row run back to back on one XCD, so the (cold) activation panel crosses the fabric once -
+  // the weight panels of two columns (2 x 2.4 MB at K = 3072) exceed the 2 400 KB slice rule above, but the workgroups of an XCD walk K
+  // in step and only a few stages of them are live at a time.  Same call: the five N = 768 GEMMs of a layer 587 / 600 -> 570 / 576 us cold,
+  // the step 21.02 / 21.01 -> 20.86 / 20.85 ms.
+  if (pl.bm == 128 && pl.bn == 384 && (a->N / pl.bn) % 2 == 0) p.gn = 2;
+#ifdef NBEST_EXPERIMENTS
+  if (pl.bn == 384) { if (const char* e = getenv("NBEST_GN384")) { const int v = atoi(e); if (v > 0 && (a->N / pl.bn) % v == 0) p.gn = v; } }
+#endif
   NB_CHECK(a->M * a->N < ((int64_t)1 << 32) || p.drop.thr16 == 0, NBEST_ERR_SHAPE, "gemm(bf16): dropout counter overflow");
   const int epi = a->epilogue;
   if (epi == NBEST_EPI_BIAS || epi == NBEST_EPI_BIAS_GELU || epi == NBEST_EPI_BIAS_DROP_RES)

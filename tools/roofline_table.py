@@ -40,6 +40,11 @@ KERNELS = [
     ("gemm2_kernel<256, 256, 2, 4, 4, true, true, 6>", 124416, "weight gradient QKV (2304x768)", gf(3 * H, H, M), (M * 4 * H * 2 + 3 * H * H * 4) / 1e6),
     ("gemm_bf16_kernel<true, true, 6>", None, "weight gradient attention-out (768x768)", gf(H, H, M), (M * 2 * H * 2 + H * H * 4) / 1e6),
     # round 3: register-epilogue kernels (256 x 256 tiles as 4 x 2 waves; 256 x 192 tiles for the N = 768 shapes)
+    # round 4: 128 x 384 tiles (2 x 4 waves of 64 x 96) took the N = 768 shapes over from 256 x 192
+    ("gemm2_kernel<128, 384, 2, 4, 5, false, false, 5>", None, "dgrad + residual: QKV (K 2304) | FFN-up (K 3072), N 768 (128x384 tiles, 5-stage ring)", (gf(M, H, 3 * H) + gf(M, H, F)) / 2, (M * (3 * H + F) / 2 * 2 + 2 * M * H * 2 + (3 * H + F) / 2 * H * 2) / 1e6),
+    ("gemm2_kernel<128, 384, 2, 4, 5, false, false, 3>", None, "forward FFN-down + bias + dropout + residual (K 3072; 128x384 tiles, 5-stage ring)", gf(M, H, F), (M * F * 2 + 2 * M * H * 2 + F * H * 2) / 1e6),
+    ("gemm2_kernel<128, 384, 2, 4, 4, false, false, 3>", None, "forward attention-out + bias + dropout + residual (K 768; 128x384 tiles)", gf(M, H, H), (M * H * 2 + 2 * M * H * 2 + H * H * 2) / 1e6),
+    ("gemm2_kernel<128, 384, 2, 4, 4, false, false, 0>", None, "dgrad attention-out (128x384 tiles)", gf(M, H, H), (2 * M * H * 2 + H * H * 2) / 1e6),
     ("gemm2_kernel<256, 192, 4, 2, 5, false, false, 5>", None, "dgrad + residual: QKV (K 2304) | FFN-up (K 3072), N 768 (256x192 tiles, 5-stage ring)", (gf(M, H, 3 * H) + gf(M, H, F)) / 2, (M * (3 * H + F) / 2 * 2 + 2 * M * H * 2 + (3 * H + F) / 2 * H * 2) / 1e6),
     ("gemm2_kernel<256, 192, 4, 2, 5, false, false, 3>", None, "forward FFN-down + bias + dropout + residual (K 3072; 256x192 tiles, 5-stage ring)", gf(M, H, F), (M * F * 2 + 2 * M * H * 2 + F * H * 2) / 1e6),
     ("gemm2_kernel<256, 192, 4, 2, 4, false, false, 5>", None, "dgrad + residual: QKV (K 2304) | FFN-up (K 3072), N 768 (256x192 tiles)", (gf(M, H, 3 * H) + gf(M, H, F)) / 2, (M * (3 * H + F) / 2 * 2 + 2 * M * H * 2 + (3 * H + F) / 2 * H * 2) / 1e6),
