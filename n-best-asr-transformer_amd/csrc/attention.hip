@@ -74,7 +74,9 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
   lse[(int64_t)bh * S + i] = lse_i;
 }
 
-// dqkv must be zeroed before the launch (dK / dV are accumulated with atomics)
+// fp32 parity path, query on the thread: dQ only.  (Until round 4 this kernel also added its dK / dV contributions with float atomics -
+// the one place left where the fp32 step was not reproducible run to run: the 6-epoch F1 trajectories of tests/test_text_pipeline.py
+// moved by +-1 pt between two runs of the same code.  dK / dV: attn_bwd_f32_kv_kernel, key on the thread, fixed summation order.)
 __global__ __launch_bounds__(128) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
                                                            const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                            const float* __restrict__ lse, float* __restrict__ dqkv, int S,
@@ -108,18 +110,56 @@ __global__ __launch_bounds__(128) void attn_bwd_f32_kernel(const float* __restri
       dp = keep ? dpt * drop.scale : 0.f;
     }
     const float ds = p * (dp - delta) * scale;
-    float* dkp = dbase + j * ld + H + h * 64;
-    float* dvp = dbase + j * ld + 2 * H + h * 64;
+    (void)pt;
 #pragma unroll
-    for (int d = 0; d < 64; ++d) {
-      dq[d] = fmaf(ds, kp[d], dq[d]);
-      atomicAdd(dkp + d, ds * q[d]);
-      atomicAdd(dvp + d, pt * dO[d]);
-    }
+    for (int d = 0; d < 64; ++d) dq[d] = fmaf(ds, kp[d], dq[d]);
   }
   float* dqp = dbase + i * ld + h * 64;
 #pragma unroll
   for (int d = 0; d < 64; ++d) dqp[d] = dq[d];
+}
+
+// dK / dV of the fp32 path: key j on the thread, queries in ascending order, every element of dK / dV written exactly once
+// (masked keys: zero) - no memset, no atomics
+__global__ __launch_bounds__(128) void attn_bwd_f32_kv_kernel(const float* __restrict__ qkv, const uint8_t* __restrict__ mask,
+                                                              const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                              const float* __restrict__ lse, float* __restrict__ dqkv, int S,
+                                                              int heads, int H, float scale, DropCfg drop) {
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int j = blockIdx.y * blockDim.x + threadIdx.x;
+  if (j >= S) return;
+  const int64_t ld = 3 * (int64_t)H;
+  const float* base = qkv + (int64_t)b * S * ld;
+  float* dbase = dqkv + (int64_t)b * S * ld;
+  const float* kp = base + j * ld + H + h * 64;
+  const float* vp = base + j * ld + 2 * H + h * 64;
+  float k[64], v[64], dk[64], dv[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) { k[d] = kp[d]; v[d] = vp[d]; dk[d] = 0.f; dv[d] = 0.f; }
+  if (mask[b * S + j]) {
+    for (int i = 0; i < S; ++i) {
+      const float* qp = base + i * ld + h * 64;
+      const float* dop = dctx + ((int64_t)b * S + i) * H + h * 64;
+      const float* op = ctx + ((int64_t)b * S + i) * H + h * 64;
+      float s = 0.f, dpt = 0.f, delta = 0.f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) { s = fmaf(qp[d], k[d], s); dpt = fmaf(dop[d], v[d], dpt); delta = fmaf(dop[d], op[d], delta); }
+      const float p = expf(s * scale - lse[(int64_t)bh * S + i]);
+      float pt = p, dp = dpt;
+      if (drop.thr16) {
+        const bool keep = nb_keep(drop, (uint32_t)((bh * S + i) * S + j));
+        pt = keep ? p * drop.scale : 0.f;
+        dp = keep ? dpt * drop.scale : 0.f;
+      }
+      const float ds = p * (dp - delta) * scale;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) { dk[d] = fmaf(ds, qp[d], dk[d]); dv[d] = fmaf(pt, dop[d], dv[d]); }
+    }
+  }
+  float* dkp = dbase + j * ld + H + h * 64;
+  float* dvp = dbase + j * ld + 2 * H + h * 64;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) { dkp[d] = dk[d]; dvp[d] = dv[d]; }
 }
 
 // =================================================================================================
@@ -1178,10 +1218,11 @@ int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, cons
   const DropCfg dc = make_drop(drop_p, seed, drop_stream);
   if (dtype == NBEST_F32) {
     NB_CHECK(S <= 512, NBEST_ERR_SHAPE, "attention_bwd(f32): S=%d > 512", S);
-    hipError_t e = hipMemsetAsync(dqkv, 0, (size_t)B * S * 3 * H * sizeof(float), st);
-    NB_CHECK(e == hipSuccess, NBEST_ERR_LAUNCH, "attention_bwd: memset failed: %s", hipGetErrorString(e));
     attn_bwd_f32_kernel<<<dim3(B * heads, (S + 127) / 128), 128, 0, st>>>((const float*)qkv, key_mask, (const float*)ctx,
                                                                           (const float*)dctx, lse, (float*)dqkv, S, heads, H, scale, dc);
+    NB_LAUNCH_CHECK();
+    attn_bwd_f32_kv_kernel<<<dim3(B * heads, (S + 127) / 128), 128, 0, st>>>((const float*)qkv, key_mask, (const float*)ctx,
+                                                                             (const float*)dctx, lse, (float*)dqkv, S, heads, H, scale, dc);
     NB_LAUNCH_CHECK();
     if (dbias) return nbest_colsum(dqkv, dbias, (int64_t)B * S, 3 * H, 3 * H, NBEST_F32, accumulate, ws, ws_bytes, stream);
     return NBEST_OK;

@@ -712,3 +712,51 @@ def test_transposed_weight_copies():
         q = _e4m3((m * s).cpu()).view(torch.uint8).to(DEV)
         assert torch.equal(w8[off:off + r * c].view(r, c), q), shapes[i]
         assert torch.equal(w8t[off:off + r * c].view(c, r), q.t()), shapes[i]
+
+
+def test_decode_into_pinned_host_rows_and_stream_stamp(labels):
+    """nbest_stc_decode with `pred` in mapped pinned HOST memory + nbest_stream_stamp behind it (the per-step prediction hand-off of
+    trainer.MetricsPipe: no hipMemcpy, no event): once the host sees the stamp, the rows it reads are the rows a device-side decode
+    of the same scores gives - over many back-to-back steps, alternating two buffers as the epoch loop does."""
+    import time
+    dls = hb.DeviceLabelSpace(labels, DEV)
+    B = 256
+    bufs = [torch.full((B, labels.n_top), -7, dtype=torch.int32).pin_memory() for _ in range(2)]
+    flags = torch.zeros(2, dtype=torch.int32).pin_memory()
+    want = []
+    for step in range(1, 41):
+        g = torch.Generator(device="cpu").manual_seed(step)
+        top = torch.rand(B, labels.n_top, generator=g).to(DEV)
+        bott = torch.rand(B, dls.n_rows - labels.n_top, generator=g).to(DEV)      # the multi-value heads' scores, concatenated
+        t = step & 1
+        hb.stc_decode(top, bott, dls, out=bufs[t])
+        hb.stream_stamp(flags[t:t + 1], step)
+        ref = hb.stc_decode(top, bott, dls)                 # the same decode into device memory
+        want.append((t, step, ref))
+        if step >= 2:                                        # consume the PREVIOUS step, as MetricsPipe does
+            pt, ps, pref = want[-2]
+            t0 = time.time()
+            while int(flags[pt]) != ps:
+                assert time.time() - t0 < 30.0, "stamp %d never arrived" % ps
+                time.sleep(0.0002)
+            assert torch.equal(bufs[pt], pref.cpu()), "step %d: host rows differ from the device decode" % ps
+    torch.cuda.synchronize()
+
+
+def test_fp8_amax_fold():
+    """nbest_fp8_amax_fold: out[t] = max over the 16 slot words of tensor t (float bits of non-negative values order like the
+    floats), slots zeroed; words outside the 16 slot positions are not touched"""
+    n, W = 7, hb.AMAX_TENSOR_WORDS
+    g = torch.Generator(device="cpu").manual_seed(3)
+    slots = torch.zeros(n, W, dtype=torch.float32)
+    pos = torch.arange(16) * (W // 16)
+    vals = torch.rand(n, 16, generator=g) * torch.tensor([1e-3, 1.0, 37.0, 448.0, 1e4, 0.0, 5.0]).view(n, 1)
+    slots[:, pos] = vals
+    slots[:, 5] = 123.0                                      # not a slot position: must survive
+    d = slots.view(torch.int32).reshape(-1).to(DEV)
+    out = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    hb.fp8_amax_fold(d, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.float32).cpu(), vals.max(dim=1).values)
+    left = d.view(torch.float32).view(n, W).cpu()
+    assert (left[:, pos] == 0).all() and (left[:, 5] == 123.0).all()

@@ -714,6 +714,36 @@ def test_packed_weight_operands_change_nothing(labels):
     assert res[0][2].abs().max() > 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_step_is_bit_reproducible_at_ragged_shapes(dtype, labels):
+    """Two runs of the same step: every gradient bit-equal, in BOTH paths.  (Round 4 found the fp32 parity path still adding its
+    attention dK / dV with float atomics - invisible at S <= 64, where one wave serves a head, and the reason why the 6-epoch F1
+    trajectories of tests/test_text_pipeline.py moved by a point between two runs of the same code.)  S = 114 and 77: several waves per
+    head in the fp32 attention kernels, ragged tiles everywhere; dropout on."""
+    import nbest_amd  # noqa: F401
+    from nbest_amd import config as ncfg, synth
+    from nbest_amd.model import NBestSTCModel
+    cfg = ncfg.bert_base(num_hidden_layers=2, vocab_size=3000)
+    sd = synth.model_state(cfg, labels, seed=8)
+    for B, S in ((16, 114), (9, 77)):
+        b = synth.nbest_batch(cfg, labels, B, S, n_best=5, seed=S, ragged=True, trans_len=20)
+        t = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+        runs = []
+        for _ in range(3):
+            m = NBestSTCModel(cfg, labels, device="cuda", compute_dtype=dtype, dropout=0.3, seed=11)
+            m.load_reference_state(sd)
+            m.train()
+            out = m.forward_backward(t["ids"], t["labels"], seg_ids=t["seg"], trans_input_ids=t["tids"], trans_seg_ids=t["tseg"], add_l2_loss=True)
+            torch.cuda.synchronize()
+            runs.append((m.arena.g.clone(), out["loss_parts"].clone(), out["final"].clone()))
+        for r in runs[1:]:
+            assert torch.equal(r[2], runs[0][2]) and torch.equal(r[1], runs[0][1])
+            if not torch.equal(r[0], runs[0][0]):
+                bad = [s_.name for s_ in m.arena.slots if not torch.equal(m.arena.view(r[0], s_.name), m.arena.view(runs[0][0], s_.name))]
+                raise AssertionError("gradients differ between two runs of the same step (%s, B %d S %d): %s" % (dtype, B, S, bad[:8]))
+        assert runs[0][0].abs().max() > 0
+
+
 def test_width_without_packed_form_uses_plain_operands(labels):
     """a bf16 model whose matrix widths have no packed form (H = 512: the N = 512 GEMMs are neither multiples of 192 nor
     >= 1024 multiples of 256) must construct - round 3 asserted in ParamArena - and run with BOTH packed tables dropped (the C side hands
