@@ -348,7 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm2_kernel(GemmP2 p) {
     }
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)opA, 0, a_bytes, 0x00020000);
-  const bool b_packed = kDirect && NT == 512 && p.Bp != nullptr && (BN != 384 || !(DIAG & 0x8000));      // workgroup-uniform
+  const bool b_packed = kDirect && NT == 512 && p.Bp != nullptr && ((BN != 384 && BN != 512) || !(DIAG & 0x8000));      // workgroup-uniform
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(b_packed ? (void*)p.Bp : (void*)opB, 0, b_packed ? p.bp_bytes : b_bytes, 0x00020000);
   const int nkt = (int)(p.K / BK);
 
@@ -1641,6 +1641,7 @@ static int forced_tile() {
     if (!strcmp(e, "256x128")) return 2;
     if (!strcmp(e, "128x128")) return 1;
     if (!strcmp(e, "128x384")) return 6;
+    if (!strcmp(e, "128x512")) return 7;
     return 0;
   }();
   return v;
@@ -1659,7 +1660,7 @@ static Plan make_plan(const nbest_gemm_args* a) {
   const int64_t t256 = ((a->M + 255) / 256) * (a->N / 128);
   pl.bm = (!a->trans_a && t256 >= 1024) ? 256 : 128;
   const int ft6 = forced_tile();
-  const int ft = (ft6 == 6) ? 0 : ft6;      // 128x384 is an ADDITIONAL choice for the N = 768 shapes: every other shape plans as usual
+  const int ft = (ft6 == 6 || ft6 == 7) ? 0 : ft6;      // 128x384 is an ADDITIONAL choice for the N = 768 shapes: every other shape plans as usual
   const bool ok256 = (a->N % 256 == 0) && (!a->trans_a || a->M % 256 == 0);
   if (ft == 3 && ok256) { pl.bm = 256; pl.bn = 256; }
   else if (ft == 4 && ok256) { pl.bm = 128; pl.bn = 256; }
@@ -1707,6 +1708,9 @@ static Plan make_plan(const nbest_gemm_args* a) {
     // holds (and which arrives packed: two adjacent 192-column blocks).  Takes over wherever 256 x 192 was chosen and N is a multiple of
     // 384.  Same call, alternating: the five N = 768 GEMMs of a layer 620 -> 586 us cold / 541 -> 510 warm; the step 21.15 / 21.22 -> 20.85 / 20.88 ms.
     if (pl.bm == 256 && pl.bn == 192 && a->N % 384 == 0 && a->K % BK == 0 && ft != 5) { pl.bm = 128; pl.bn = 384; }
+    // 128 x 512 (2 x 4 waves of 64 x 128, 40 KB stages: all 160 KB of LDS): the same turn for the N = 1024 shapes of xlm-roberta-large, which plan
+    // 256 x 256 (4 tile columns): xlm-roberta-large S = 256, 64 utterances 1 585 -> 1 622 utt/s (same call, twice).  NBEST_TILE=256x256 keeps the old plan.
+    if (ft6 != 3 && pl.bm == 256 && pl.bn == 256 && !a->trans_a && !a->trans_b && epi192 && a->N % 512 == 0 && a->N <= 2048 && a->K % BK == 0) { pl.bm = 128; pl.bn = 512; }
   }
   const int64_t tiles = ((a->M + pl.bm - 1) / pl.bm) * (a->N / pl.bn);
   const int64_t slots = (pl.bn >= 192) ? 256 : 512;   // workgroups resident at once
@@ -1775,7 +1779,7 @@ bool nbest_gemm_bf16_v2_wins(const nbest_gemm_args* a) {
   // column sums fused into an epilogue other than x GELU': the generation-1 kernel carries them for every epilogue (no caller in the training step)
   if (a->colsum_out && a->epilogue != NBEST_EPI_DGELU && a->epilogue != NBEST_EPI_F32_SPLITK && !a->trans_a && !a->trans_b) return false;
   const Plan pl = make_plan(a);
-  return pl.bm == 256 || (pl.bm == 128 && pl.bn == 384) || (forced_tile() != 0 && forced_tile() != 6);
+  return pl.bm == 256 || (pl.bm == 128 && pl.bn >= 384) || (forced_tile() != 0 && forced_tile() < 6);
 }   // 256x128 ring or 256x256 ping-pong
 
 int nbest_internal_partial_rows_sum(const float* part, int nrows, int N, float* out, int accumulate, hipStream_t st);
@@ -1813,7 +1817,7 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
   p.colpart = nullptr;
   p.A2 = p.B2 = nullptr; p.lda2 = p.ldb2 = p.m_split = 0; p.a2_bytes = p.b2_bytes = 0;
   p.Bp = nullptr; p.bp_bytes = 0; p.bp_bn = 0;
-  if (a->B_packed && ((a->b_pack_bn == pl.bn && pl.bm == 256 && (pl.bn == 256 || pl.bn == 192)) || (pl.bm == 128 && pl.bn == 384 && a->b_pack_bn == 192)) &&
+  if (a->B_packed && ((a->b_pack_bn == pl.bn && pl.bm == 256 && (pl.bn == 256 || pl.bn == 192)) || (pl.bm == 128 && pl.bn == 384 && a->b_pack_bn == 192) || (pl.bm == 128 && pl.bn == 512 && a->b_pack_bn == 256)) &&
       !a->trans_a && !a->trans_b &&
       a->epilogue != NBEST_EPI_F32_SPLITK && a->K % BK == 0 && a->N * a->K * 2 < ((int64_t)1 << 32) && ((uintptr_t)a->B_packed & 15) == 0) {
     p.Bp = (const bf16*)a->B_packed;
@@ -1860,7 +1864,7 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
   // the weight panels of two columns (2 x 2.4 MB at K = 3072) exceed the 2 400 KB slice rule above, but the workgroups of an XCD walk K
   // in step and only a few stages of them are live at a time.  Same call: the five N = 768 GEMMs of a layer 587 / 600 -> 570 / 576 us cold,
   // the step 21.02 / 21.01 -> 20.86 / 20.85 ms.
-  if (pl.bm == 128 && pl.bn == 384 && (a->N / pl.bn) % 2 == 0) p.gn = 2;
+  if (pl.bm == 128 && pl.bn >= 384 && (a->N / pl.bn) % 2 == 0) p.gn = 2;
 #ifdef NBEST_EXPERIMENTS
   if (pl.bn == 384) { if (const char* e = getenv("NBEST_GN384")) { const int v = atoi(e); if (v > 0 && (a->N / pl.bn) % v == 0) p.gn = v; } }
 #endif
@@ -1878,7 +1882,9 @@ static int gemm_v2_impl(const nbest_gemm_args* a, const nbest_gemm_args* b2, int
   const int grid = p.tiles_m * p.tiles_n * p.splits;
   int rc, wave_rows = 2;   // wave rows per tile = partial rows of the fused column sums
   NB_CHECK(a->N % pl.bn == 0, NBEST_ERR_SHAPE, "gemm(bf16): N=%lld is not a multiple of the %d-column tile", (long long)a->N, pl.bn);
-  if (pl.bm == 128 && pl.bn == 384) {
+  if (pl.bm == 128 && pl.bn == 512) {
+    rc = launch2<128, 512, 2, 4, 4, false, false>(p, epi, grid, st);
+  } else if (pl.bm == 128 && pl.bn == 384) {
     if (a->K >= 2048 || stages5_enabled()) rc = launch2<128, 384, 2, 4, 5, false, false>(p, epi, grid, st);
     else rc = launch2<128, 384, 2, 4, 4, false, false>(p, epi, grid, st);
   } else if (pl.bm == 256 && pl.bn == 192) {
