@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """soak: a few hundred full-size training steps (bf16, or the fp8w mode) with dropout on fresh synthetic batches - loss must fall
-and every parameter / moment stay finite.  python tools/soak.py [steps] [bf16|fp8w]"""
+and every parameter / moment stay finite.  python tools/soak.py [steps] [bf16|fp8w] [seed]"""
 import os
 import sys
 import torch
@@ -15,10 +15,11 @@ from nbest_amd.trainer import train_step
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 fp8 = len(sys.argv) > 2 and sys.argv[2] == "fp8w"
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 999
 labels = ncfg.LabelSpace.from_json(os.path.join(ROOT, "tests", "golden", "label_space.json"))
 cfg = ncfg.bert_base()
-m = NBestSTCModel(cfg, labels, device="cuda:0", compute_dtype=torch.bfloat16, dropout=0.3, seed=999, fp8_forward=fp8)
-m.load_reference_state(synth.model_state(cfg, labels, seed=999))
+m = NBestSTCModel(cfg, labels, device="cuda:0", compute_dtype=torch.bfloat16, dropout=0.3, seed=seed, fp8_forward=fp8)
+m.load_reference_state(synth.model_state(cfg, labels, seed=seed))
 m.train()
 opt = HipBertAdam(m, lr=3e-5, bert_lr=3e-5, warmup=0.1, t_total=steps)
 pool = []
