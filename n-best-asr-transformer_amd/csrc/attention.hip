@@ -765,6 +765,249 @@ __global__ __launch_bounds__((NKB <= 4 ? 4 : 8) * 64, 2) void attn_bwd2_bf16_ker
 }
 
 
+// ---- backward, third structure (round 4): 96 < S <= 128, EIGHT waves of 16 keys on v_mfma_f32_16x16x32_bf16 ------------------------
+// tools/attn_scale.py: one workgroup of the second structure alone on a CU, operands cached, takes ~15 us for ~3 us of instruction issue
+// per wave - a chain of dependent LDS read -> MFMA -> exp -> pack -> MFMA steps on ONE 32 x 32 tile per wave, at two waves per SIMD (223
+// registers, 67 KiB of LDS).  Here a wave owns 16 keys: half the accumulators (dK, dV: 16 + 16 registers), half the elements per
+// lane, and the dQ product of a query block is EIGHT 16 x 16 tiles - one per wave - instead of 16 MFMAs on one wave while the others
+// wait at the barrier.  Same LDS images (Q | K | dO [128][64] bf16, chunk ^= gsw(row); dS image [key][64 q], two 32-query halves), same
+// "key on the lane" arithmetic: S = Q K^T and dP = dO V^T tiles are D[16 q][16 keys] - a lane holds ONE key (lane & 15) and four
+// consecutive queries per register quad; P^T and dS^T feed the dV / dK MFMAs as the A operand straight from the accumulators (k order
+// = this lane group's queries {4g + e, 16 + 4g + e}; dO / Q fetched with the matching permuted transposed read).
+__device__ __forceinline__ bf16x8 row_frag16(const char* tile, int row0, int ks, int lane) {   // rows row0 + (l & 15), k = 32 ks + 8 (l >> 4) + j
+  const int row = row0 + (lane & 15);
+  const int c = 4 * ks + (lane >> 4);
+  return *(const bf16x8*)(tile + row * 128 + ((c ^ gsw(row)) << 4));
+}
+// operand with k along the image ROWS: lane l -> column col0 + (l & 15); natural: k = kbase + 8 (l >> 4) + j; PERMUTED: k = kbase + 4 (l >> 4) + j
+// for j < 4 and kbase + 16 + 4 (l >> 4) + (j - 4) for j >= 4 (the query order of an accumulator pair used as the A operand)
+template <bool PERMUTED>
+__device__ __forceinline__ bf16x8 tr_frag16(const char* tile, int kbase, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15, qq = i >> 2, pq = i & 3;
+  const int col = col0 + 4 * pq;
+  const int r1 = kbase + (PERMUTED ? 4 * g : 8 * g) + qq;
+  const int r2 = r1 + (PERMUTED ? 16 : 4);
+  const char* a1 = tile + r1 * 128 + (((col >> 3) ^ gsw(r1)) << 4) + ((col & 4) ? 8 : 0);
+  const char* a2 = tile + r2 * 128 + (((col >> 3) ^ gsw(r2)) << 4) + ((col & 4) ? 8 : 0);
+  const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a1);
+  const bf16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)a2);
+  bf16x8 o;
+  o[0] = v1[0]; o[1] = v1[1]; o[2] = v1[2]; o[3] = v1[3]; o[4] = v2[0]; o[5] = v2[1]; o[6] = v2[2]; o[7] = v2[3];
+  return o;
+}
+
+template <bool KB>
+__global__ __launch_bounds__(512, 4) void attn_bwd3_bf16_kernel(
+    const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask, const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
+    const float* __restrict__ lse, bf16* __restrict__ dqkv, float* __restrict__ colpart, int S, int heads, int H, float scale,
+    DropCfg drop, Fp8Grad f8, const uint32_t* __restrict__ keep) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NKB = 4, Sp = 128, NW = 8, NT = 512;
+  char* Qt = lds;
+  char* Kt = Qt + Sp * 128;
+  char* dOt = Kt + Sp * 128;
+  char* dST = dOt + Sp * 128;
+  float* lse_s = (float*)(dST + Sp * 128);
+  float* del_s = lse_s + Sp;
+  uint32_t* kw_s = (uint32_t*)(del_s + Sp);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const int ld = 3 * H;
+  const bf16* base = qkv + (int64_t)b * S * ld;
+  const bf16* dobase = dctx + (int64_t)b * S * H;
+  const bf16* obase = ctx + (int64_t)b * S * H;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (uint32_t)(S * ld * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, (uint32_t)(S * H * 2), 0x00020000);
+  stage_rows(rs, Qt, Sp, h * 64, ld, tid, NT);
+  stage_rows(rs, Kt, Sp, H + h * 64, ld, tid, NT);
+  stage_rows(rsd, dOt, Sp, h * 64, H, tid, NT);
+  for (int k = tid; k < Sp; k += NT) lse_s[k] = (k < S) ? lse[(int64_t)bh * S + k] * 1.4426950408889634f : INFINITY;
+  if (KB) {
+    for (int i = tid; i < NKB * Sp; i += NT) kw_s[i] = keep[(int64_t)bh * NKB * Sp + i];
+  }
+  {  // delta[q] = sum_d dO[q][d] * O[q][d]; four threads per row
+    const int r = tid >> 2, quarter = tid & 3;
+    float sdel = 0.f;
+    if (r < S) {
+      const bf16* dp = dobase + (int64_t)r * H + h * 64 + 16 * quarter;
+      const bf16* op = obase + (int64_t)r * H + h * 64 + 16 * quarter;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float a[8], o[8];
+        Vec8<bf16>::load(dp + 8 * c, a);
+        Vec8<bf16>::load(op + 8 * c, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sdel = fmaf(a[j], o[j], sdel);
+      }
+    }
+    sdel += __shfl_xor(sdel, 1, 64);
+    sdel += __shfl_xor(sdel, 2, 64);
+    if (quarter == 0) del_s[r] = sdel;
+  }
+  // this wave's 16 keys: mask bit and V row fragments straight from HBM (B operand of dP = dO V^T: column = key, k = d)
+  const int key = 16 * wave + c16;
+  const bool kvalid = key < S;
+  const float mk = (kvalid && mask[b * S + key]) ? 0.f : -INFINITY;
+  const uint32_t lanebit = 1u << (key & 31);
+  const float sl2 = scale * 1.4426950408889634f;
+  bf16x8 kf[2], vf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const i32x4 raw = kvalid ? *(const i32x4*)(base + (int64_t)key * ld + 2 * H + h * 64 + 32 * ks + 8 * g) : i32x4{0, 0, 0, 0};
+    vf[ks] = __builtin_bit_cast(bf16x8, raw);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) kf[ks] = row_frag16(Kt, 16 * wave, ks, lane);
+  f32x4 dk[4], dv[4], dq[NKB];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { dk[t] = f32x4{0, 0, 0, 0}; dv[t] = f32x4{0, 0, 0, 0}; dq[t] = f32x4{0, 0, 0, 0}; }
+  char* dsrow = dST + key * 128;
+  const int dsg = gsw(key);
+  const int qt_mine = wave >> 2, dt_mine = wave & 3;          // this wave's 16 x 16 tile of every query block's dQ
+
+#pragma unroll
+  for (int qb = 0; qb < NKB; ++qb) {
+    const int half = qb & 1;
+    f32x4 sa[2], da[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      sa[qt] = f32x4{0, 0, 0, 0}; da[qt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        sa[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag16(Qt, 32 * qb + 16 * qt, ks, lane), kf[ks], sa[qt], 0, 0, 0);
+        da[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag16(dOt, 32 * qb + 16 * qt, ks, lane), vf[ks], da[qt], 0, 0, 0);
+      }
+    }
+    bf16x8 pa, dsa;      // P^T and dS^T as A operands: element j < 4 = query 4 g + j of tile 0, j >= 4 = query 16 + 4 g + (j - 4)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qoff = 32 * qb + 16 * qt + 4 * g;
+      const f32x4 l4 = *(const f32x4*)(lse_s + qoff);
+      const f32x4 d4 = *(const f32x4*)(del_s + qoff);
+      i32x4 k4 = {0, 0, 0, 0};
+      if (KB) k4 = *(const i32x4*)(kw_s + (wave >> 1) * Sp + qoff);
+      bf16x4 pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sa[qt][e], sl2, mk - l4[e]));
+        float pt = pv, dp = da[qt][e];
+        if (KB) {
+          const float kf_ = ((uint32_t)k4[e] & lanebit) ? drop.scale : 0.f;
+          pt = pv * kf_;
+          dp = dp * kf_;
+        } else if (drop.thr16) {
+          const bool keep_ = nb_keep(drop, (uint32_t)((bh * S + qoff + e) * S + key));
+          pt = keep_ ? pv * drop.scale : 0.f;
+          dp = keep_ ? dp * drop.scale : 0.f;
+        }
+        const float ds = pv * (dp - d4[e]) * scale;
+        pa[4 * qt + e] = (bf16)pt;
+        dsa[4 * qt + e] = (bf16)ds;
+        pk[e] = (bf16)ds;
+      }
+      const int col = 32 * half + 16 * qt + 4 * g;
+      *(bf16x4*)(dsrow + (((col >> 3) ^ dsg) << 4) + ((col & 4) ? 8 : 0)) = pk;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, tr_frag16<true>(dOt, 32 * qb, 16 * dt, lane), dv[dt], 0, 0, 0);
+      dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, tr_frag16<true>(Qt, 32 * qb, 16 * dt, lane), dk[dt], 0, 0, 0);
+    }
+    __syncthreads();   // the dS image half of query block qb is complete (and the other half is free again)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)   // dQ[qb] tile (qt_mine, dt_mine) += dS[16 q][32 keys] . K[32 keys][16 d]
+      dq[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag16<false>(dST, 32 * ks, 32 * half + 16 * qt_mine, lane),
+                                                       tr_frag16<false>(Kt, 32 * ks, 16 * dt_mine, lane), dq[qb], 0, 0, 0);
+  }
+  __syncthreads();  // everyone is done with Qt / Kt / dOt / the dS image: reuse them as output images
+  if (colpart) {    // bias gradient: column sums of dQ | dK | dV over the rows of this (sample, head), fixed order
+    float* cs = (float*)dST;          // [8 waves][2][64] for dK, dV, then [8 waves][16] for dQ
+    float* csq = cs + NW * 2 * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      float xk = (dk[dt][0] + dk[dt][1]) + (dk[dt][2] + dk[dt][3]);
+      float xv = (dv[dt][0] + dv[dt][1]) + (dv[dt][2] + dv[dt][3]);
+      xk += __shfl_xor(xk, 16, 64); xk += __shfl_xor(xk, 32, 64);
+      xv += __shfl_xor(xv, 16, 64); xv += __shfl_xor(xv, 32, 64);
+      if (g == 0) { cs[(wave * 2 + 0) * 64 + 16 * dt + c16] = xk; cs[(wave * 2 + 1) * 64 + 16 * dt + c16] = xv; }
+    }
+    float xq = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < NKB; ++qb) xq += (dq[qb][0] + dq[qb][1]) + (dq[qb][2] + dq[qb][3]);
+    xq += __shfl_xor(xq, 16, 64); xq += __shfl_xor(xq, 32, 64);
+    if (g == 0) csq[wave * 16 + c16] = xq;
+    __syncthreads();
+    if (tid < 192) {
+      const int which = tid >> 6, dcol = tid & 63;
+      float x = 0.f;
+      if (which == 0) x = csq[(dcol >> 4) * 16 + (dcol & 15)] + csq[((dcol >> 4) + 4) * 16 + (dcol & 15)];   // q tiles 0 and 1 of this d tile
+      else {
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) x += cs[(w2 * 2 + (which - 1)) * 64 + dcol];
+      }
+      colpart[(int64_t)b * 3 * H + which * H + h * 64 + dcol] = x;
+    }
+    __syncthreads();
+  }
+  // accumulators -> plain [row][64] bf16 images over Qt / Kt / dOt, then 16-byte row stores (and the optional e4m3 copies / amax)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 16 * wave + 4 * g + e;
+      *(bf16*)(Kt + row * 128 + (16 * dt + c16) * 2) = (bf16)dk[dt][e];
+      *(bf16*)(dOt + row * 128 + (16 * dt + c16) * 2) = (bf16)dv[dt][e];
+    }
+#pragma unroll
+  for (int qb = 0; qb < NKB; ++qb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      *(bf16*)(Qt + (32 * qb + 16 * qt_mine + 4 * g + e) * 128 + (16 * dt_mine + c16) * 2) = (bf16)dq[qb][e];
+  __syncthreads();
+  {
+    const int64_t goff = (int64_t)b * S * ld + h * 64;
+    bf16* gq = dqkv ? dqkv + goff : nullptr;
+    uint8_t* g8 = f8.out8 ? f8.out8 + goff : nullptr;
+    const float s8 = fp8_grad_scale(f8.amax_prev);
+    const bool am = f8.amax_new != nullptr;
+    float amax8 = 0.f;
+    const char* imgs[3] = {Qt, Kt, dOt};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = it * NT + tid, row = p >> 3, ch = p & 7;
+        if (row < S) {
+          const i32x4 v = *(const i32x4*)(imgs[t] + row * 128 + ch * 16);
+          if (gq) *(i32x4*)(gq + (int64_t)row * ld + t * H + ch * 8) = v;
+          if (g8 || am) {
+            const bf16x8 bb = __builtin_bit_cast(bf16x8, v);
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)bb[e];
+            if (am) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) amax8 = fmaxf(amax8, fabsf(f[e]));
+            }
+            if (g8) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] *= s8;
+              *(i32x2*)(g8 + (int64_t)row * ld + t * H + ch * 8) = i32x2{(int)fp8_pack4(f), (int)fp8_pack4(f + 4)};
+            }
+          }
+        }
+      }
+    }
+    if (am) {
+      amax8 = wave_max(amax8);
+      if (lane == 0) amax_update(f8.amax_new, amax8);
+    }
+  }
+}
+
+
 // =================================================================================================
 // long sequences, 256 < S <= 512 (BERT's position table ends at 512; the reference never truncates,
 // /root/reference/utils/bert_xlnet_inputs.py:87-94).  Same tiles, operand tricks and LDS images as above, but
@@ -1251,6 +1494,23 @@ int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, cons
     return NBEST_OK;
   }
 #endif
+  bool third = (nkb == 4);                 // 96 < S <= 128: eight 16-key waves (attn_bwd3_bf16_kernel)
+#ifdef NBEST_EXPERIMENTS
+  { static const int second = [] { const char* e = getenv("NBEST_ATTN_BWD"); return (e && e[0] == '2') ? 1 : 0; }(); if (second) third = false; }
+#endif
+  if (third) {
+    const size_t sm = bwd2_lds_bytes(4);
+    if (keep && dc.thr16) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd3_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+      attn_bwd3_bf16_kernel<true><<<B * heads, 512, sm, st>>>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, S, heads, H, scale, dc, f8, keep);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_bwd3_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+      attn_bwd3_bf16_kernel<false><<<B * heads, 512, sm, st>>>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, S, heads, H, scale, dc, f8, nullptr);
+    }
+    NB_LAUNCH_CHECK();
+    if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
+    return NBEST_OK;
+  }
 #define F(N) case N: launch_bwd2<N>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, B, S, heads, H, scale, dc, st, f8, keep); break;
   switch (nkb) { F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) }
 #undef F
