@@ -59,6 +59,7 @@ KERNELS = [
     ("gemm2_kernel<256, 256, 2, 4, 4, false, false, 4>", None, "dgrad FFN-down x GELU' (+ fused db1)", gf(M, F, H), (M * H * 2 + 2 * M * F * 2 + F * H * 2) / 1e6),
     ("gemm2_kernel<256, 256, 2, 4, 4, false, false, 1>", None, "forward QKV + bias", gf(M, 3 * H, H), (M * H * 2 + M * 3 * H * 2 + 3 * H * H * 2) / 1e6),
     ("gemm_bf16_kernel<false, false, 0>", None, "dgrad attention-out", gf(M, H, H), (2 * M * H * 2 + H * H * 2) / 1e6),
+    ("attn_bwd3_bf16_kernel", None, "attention backward, 16-key waves (recompute P; dQ dK dV + bias gradient)", 5 * 4.0 * S * S * 64 * B * HEADS / 2 / 1e9 * 1.0, (M * 3 * H * 2 * 2 + 2 * M * H * 2) / 1e6),
     ("attn_bwd2_bf16_kernel", None, "attention backward (recompute P; dQ dK dV + bias gradient)", 5 * 4.0 * S * S * 64 * B * HEADS / 2 / 1e9 * 1.0, (M * 3 * H * 2 * 2 + 2 * M * H * 2) / 1e6),
     ("attn_fwd_bf16_kernel", None, "attention forward", 2 * 2.0 * S * S * 64 * B * HEADS / 1e9, (M * 3 * H * 2 + M * H * 2) / 1e6),
     ("ln_bwd_fast_kernel", None, "LayerNorm backward (+ dropout mask, dgamma dbeta dbias partials)", None, (4 * M * H * 2) / 1e6),
