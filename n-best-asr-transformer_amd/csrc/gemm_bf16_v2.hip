@@ -1711,6 +1711,12 @@ static Plan make_plan(const nbest_gemm_args* a) {
     // 128 x 512 (2 x 4 waves of 64 x 128, 40 KB stages: all 160 KB of LDS): the same turn for the N = 1024 shapes of xlm-roberta-large, which plan
     // 256 x 256 (4 tile columns): xlm-roberta-large S = 256, 64 utterances 1 585 -> 1 622 utt/s (same call, twice).  NBEST_TILE=256x256 keeps the old plan.
     if (ft6 != 3 && pl.bm == 256 && pl.bn == 256 && !a->trans_a && !a->trans_b && epi192 && a->N % 512 == 0 && a->N <= 2048 && a->K % BK == 0) { pl.bm = 128; pl.bn = 512; }
+#ifdef NBEST_EXPERIMENTS
+    {   // NBEST_T512ALL=1: every 256 x 256 plan with N % 512 == 0, GELU epilogues included
+      static const int all = [] { const char* e = getenv("NBEST_T512ALL"); return (e && e[0] == '1') ? 1 : 0; }();
+      if (all && pl.bm == 256 && pl.bn == 256 && !a->trans_a && !a->trans_b && a->epilogue != NBEST_EPI_F32_SPLITK && a->N % 512 == 0 && a->K % BK == 0) { pl.bm = 128; pl.bn = 512; }
+    }
+#endif
   }
   const int64_t tiles = ((a->M + pl.bm - 1) / pl.bm) * (a->N / pl.bn);
   const int64_t slots = (pl.bn >= 192) ? 256 : 512;   // workgroups resident at once
