@@ -796,13 +796,16 @@ __device__ __forceinline__ bf16x8 tr_frag16(const char* tile, int kbase, int col
   return o;
 }
 
-template <bool KB>
-__global__ __launch_bounds__(512, 4) void attn_bwd3_bf16_kernel(
+// NKB = 4: 96 < S <= 128, 8 waves.  NKB = 8: 224 < S <= 256, 16 waves (one workgroup per CU: 136 KiB of LDS, four waves per SIMD); the dQ
+// product of a query block is still eight tiles over all 256 keys - waves 0-7 take the even query blocks, waves 8-15 the odd ones.
+template <int NKB, bool KB>
+__global__ __launch_bounds__(NKB * 128, 4) void attn_bwd3_bf16_kernel(
     const bf16* __restrict__ qkv, const uint8_t* __restrict__ mask, const bf16* __restrict__ ctx, const bf16* __restrict__ dctx,
     const float* __restrict__ lse, bf16* __restrict__ dqkv, float* __restrict__ colpart, int S, int heads, int H, float scale,
     DropCfg drop, Fp8Grad f8, const uint32_t* __restrict__ keep) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int NKB = 4, Sp = 128, NW = 8, NT = 512;
+  static_assert(NKB == 4 || NKB == 8, "attn_bwd3: 8 or 16 waves of 16 keys");
+  constexpr int Sp = NKB * 32, NW = 2 * NKB, NT = NW * 64;
   char* Qt = lds;
   char* Kt = Qt + Sp * 128;
   char* dOt = Kt + Sp * 128;
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_bf16_kernel(
     }
     sdel += __shfl_xor(sdel, 1, 64);
     sdel += __shfl_xor(sdel, 2, 64);
-    if (quarter == 0) del_s[r] = sdel;
+    if (quarter == 0 && r < Sp) del_s[r] = sdel;
   }
   // this wave's 16 keys: mask bit and V row fragments straight from HBM (B operand of dP = dO V^T: column = key, k = d)
   const int key = 16 * wave + c16;
@@ -860,12 +863,15 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_bf16_kernel(
   __syncthreads();
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) kf[ks] = row_frag16(Kt, 16 * wave, ks, lane);
-  f32x4 dk[4], dv[4], dq[NKB];
+  f32x4 dk[4], dv[4], dq[4];             // dq: this wave's tile of query blocks 0..3 (NKB = 4) / 2 i + khalf (NKB = 8)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { dk[t] = f32x4{0, 0, 0, 0}; dv[t] = f32x4{0, 0, 0, 0}; dq[t] = f32x4{0, 0, 0, 0}; }
+  for (int t = 0; t < 4; ++t) { dk[t] = f32x4{0, 0, 0, 0}; dv[t] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) dq[t] = f32x4{0, 0, 0, 0};
   char* dsrow = dST + key * 128;
   const int dsg = gsw(key);
-  const int qt_mine = wave >> 2, dt_mine = wave & 3;          // this wave's 16 x 16 tile of every query block's dQ
+  const int qt_mine = (wave & 7) >> 2, dt_mine = wave & 3;    // this wave's 16 x 16 tile of every query block's dQ
+  const int khalf = wave >> 3;                                // NKB = 8: 0 = this wave multiplies the even query blocks' dQ, 1 = the odd ones'
 
 #pragma unroll
   for (int qb = 0; qb < NKB; ++qb) {
@@ -916,14 +922,17 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_bf16_kernel(
       dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, tr_frag16<true>(Qt, 32 * qb, 16 * dt, lane), dk[dt], 0, 0, 0);
     }
     __syncthreads();   // the dS image half of query block qb is complete (and the other half is free again)
+    if (NKB == 4 || (qb & 1) == khalf) {   // dQ[qb] tile (qt_mine, dt_mine) = dS[16 q][all keys] . K[keys][16 d]
+      const int slot = (NKB == 4) ? qb : (qb >> 1);      // (qb is an unrolled loop counter: a register index at compile time)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)   // dQ[qb] tile (qt_mine, dt_mine) += dS[16 q][32 keys] . K[32 keys][16 d]
-      dq[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag16<false>(dST, 32 * ks, 32 * half + 16 * qt_mine, lane),
-                                                       tr_frag16<false>(Kt, 32 * ks, 16 * dt_mine, lane), dq[qb], 0, 0, 0);
+      for (int ks = 0; ks < NKB; ++ks)
+        dq[slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag16<false>(dST, 32 * ks, 32 * half + 16 * qt_mine, lane),
+                                                           tr_frag16<false>(Kt, 32 * ks, 16 * dt_mine, lane), dq[slot], 0, 0, 0);
+    }
   }
   __syncthreads();  // everyone is done with Qt / Kt / dOt / the dS image: reuse them as output images
   if (colpart) {    // bias gradient: column sums of dQ | dK | dV over the rows of this (sample, head), fixed order
-    float* cs = (float*)dST;          // [8 waves][2][64] for dK, dV, then [8 waves][16] for dQ
+    float* cs = (float*)dST;          // [NW waves][2][64] for dK, dV, then [NW waves][16] for dQ
     float* csq = cs + NW * 2 * 64;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -935,14 +944,17 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_bf16_kernel(
     }
     float xq = 0.f;
 #pragma unroll
-    for (int qb = 0; qb < NKB; ++qb) xq += (dq[qb][0] + dq[qb][1]) + (dq[qb][2] + dq[qb][3]);
+    for (int t = 0; t < 4; ++t) xq += (dq[t][0] + dq[t][1]) + (dq[t][2] + dq[t][3]);
     xq += __shfl_xor(xq, 16, 64); xq += __shfl_xor(xq, 32, 64);
     if (g == 0) csq[wave * 16 + c16] = xq;
     __syncthreads();
     if (tid < 192) {
       const int which = tid >> 6, dcol = tid & 63;
       float x = 0.f;
-      if (which == 0) x = csq[(dcol >> 4) * 16 + (dcol & 15)] + csq[((dcol >> 4) + 4) * 16 + (dcol & 15)];   // q tiles 0 and 1 of this d tile
+      if (which == 0) {                                     // the waves that hold a tile of this d tile: dt, dt + 4 (, dt + 8, dt + 12)
+#pragma unroll
+        for (int w2 = 0; w2 < NW / 4; ++w2) x += csq[((dcol >> 4) + 4 * w2) * 16 + (dcol & 15)];
+      }
       else {
 #pragma unroll
         for (int w2 = 0; w2 < NW; ++w2) x += cs[(w2 * 2 + (which - 1)) * 64 + dcol];
@@ -961,10 +973,12 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_bf16_kernel(
       *(bf16*)(dOt + row * 128 + (16 * dt + c16) * 2) = (bf16)dv[dt][e];
     }
 #pragma unroll
-  for (int qb = 0; qb < NKB; ++qb)
+  for (int t = 0; t < 4; ++t) {
+    const int qb = (NKB == 4) ? t : 2 * t + khalf;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      *(bf16*)(Qt + (32 * qb + 16 * qt_mine + 4 * g + e) * 128 + (16 * dt_mine + c16) * 2) = (bf16)dq[qb][e];
+      *(bf16*)(Qt + (32 * qb + 16 * qt_mine + 4 * g + e) * 128 + (16 * dt_mine + c16) * 2) = (bf16)dq[t][e];
+  }
   __syncthreads();
   {
     const int64_t goff = (int64_t)b * S * ld + h * 64;
@@ -977,7 +991,7 @@ __global__ __launch_bounds__(512, 4) void attn_bwd3_bf16_kernel(
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < (Sp * 8) / NT; ++it) {
         const int p = it * NT + tid, row = p >> 3, ch = p & 7;
         if (row < S) {
           const i32x4 v = *(const i32x4*)(imgs[t] + row * 128 + ch * 16);
@@ -1494,19 +1508,30 @@ int nbest_internal_attention_bwd8(const void* qkv, const uint8_t* key_mask, cons
     return NBEST_OK;
   }
 #endif
-  bool third = (nkb == 4);                 // 96 < S <= 128: eight 16-key waves (attn_bwd3_bf16_kernel)
+  // 96 < S <= 128: 16-key waves (attn_bwd3_bf16_kernel).  The 16-wave form for 224 < S <= 256 is correct (tests) but measured 0.7 - 0.9 % SLOWER on the
+  // S = 256 steps than the second structure (one workgroup per CU either way, 25 spilled registers): experiment builds only (NBEST_ATTN_BWD=3).
+  bool third = (nkb == 4);
 #ifdef NBEST_EXPERIMENTS
-  { static const int second = [] { const char* e = getenv("NBEST_ATTN_BWD"); return (e && e[0] == '2') ? 1 : 0; }(); if (second) third = false; }
+  {
+    static const int forced = [] { const char* e = getenv("NBEST_ATTN_BWD"); return (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0; }();
+    if (forced == 2) third = false;
+    if (forced == 3 && nkb == 8) third = true;
+  }
 #endif
   if (third) {
-    const size_t sm = bwd2_lds_bytes(4);
-    if (keep && dc.thr16) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd3_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-      attn_bwd3_bf16_kernel<true><<<B * heads, 512, sm, st>>>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, S, heads, H, scale, dc, f8, keep);
-    } else {
-      (void)hipFuncSetAttribute((const void*)attn_bwd3_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-      attn_bwd3_bf16_kernel<false><<<B * heads, 512, sm, st>>>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, colpart, S, heads, H, scale, dc, f8, nullptr);
-    }
+    const size_t sm = bwd2_lds_bytes(nkb);
+    const bool kb = keep && dc.thr16;
+#define G(N, K_)                                                                                                                        \
+    do {                                                                                                                                \
+      (void)hipFuncSetAttribute((const void*)attn_bwd3_bf16_kernel<N, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);        \
+      attn_bwd3_bf16_kernel<N, K_><<<B * heads, N * 128, sm, st>>>((const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, \
+                                                                   (bf16*)dqkv, colpart, S, heads, H, scale, dc, f8, K_ ? keep : nullptr); \
+    } while (0)
+    if (nkb == 4) { if (kb) G(4, true); else G(4, false); }
+#ifdef NBEST_EXPERIMENTS
+    else { if (kb) G(8, true); else G(8, false); }
+#endif
+#undef G
     NB_LAUNCH_CHECK();
     if (dbias) return nbest_internal_partial_rows_sum(colpart, B, 3 * H, dbias, accumulate, st);
     return NBEST_OK;

@@ -338,7 +338,7 @@ def _attn_ref(qkv, mask, B, S, heads):
 
 @pytest.mark.parametrize("dtype,S", [(torch.float32, 48), (torch.float32, 37), (torch.bfloat16, 128), (torch.bfloat16, 48),
                                      (torch.bfloat16, 37), (torch.bfloat16, 96), (torch.bfloat16, 100), (torch.bfloat16, 114), (torch.bfloat16, 160), (torch.bfloat16, 256),
-                                     (torch.bfloat16, 201),
+                                     (torch.bfloat16, 201), (torch.bfloat16, 230),
                                      # long-sequence kernels (256 < S <= 512): ragged last key block, 9 / 10 / 12 / 16 key blocks
                                      (torch.bfloat16, 257), (torch.bfloat16, 300), (torch.bfloat16, 384), (torch.bfloat16, 512),
                                      (torch.float32, 300)])
@@ -377,7 +377,7 @@ def test_attention_fwd_bf16_long(S):
     close("attn_fwd bf16 lse S=%d" % S, lse, lse_ref, 1e-2)
 
 
-@pytest.mark.parametrize("S", [64, 37, 128, 109, 160, 300, 333])
+@pytest.mark.parametrize("S", [64, 37, 128, 109, 160, 256, 239, 300, 333])
 def test_attention_dropout_fwd_bwd_consistent(S):
     """bf16 MFMA and fp32 VALU kernels must draw the SAME mask from (seed, stream); the backward of
     each must be the gradient of its own forward (checked through the fp32 kernel by finite differences
